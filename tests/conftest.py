@@ -1,0 +1,18 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def mock_no_gpu(monkeypatch):
+    """Same fixture the reference suite uses (/root/reference/test/conftest.py:3-5)."""
+    monkeypatch.setattr("torch.cuda.is_available", lambda: False)
