@@ -1,0 +1,193 @@
+/* pgibbs.h -- C ABI of the MI355X-native Gibbs-sampling engine for masked protein LMs.
+ *
+ * Plain pointers and sizes only (no torch / C++ types), so any FFI (ctypes, cffi, cgo, JNI ...)
+ * can bind it.  Every entry point names the reference interface it replaces; paths are relative
+ * to the reference tree (seanrjohnson/protein_gibbs_sampler, `pgen` 0.2.3).
+ *
+ * Conventions
+ *   - every function returning int returns PG_OK (0) or a PG_ERR_* code; pg_last_error() gives the
+ *     message of the last failure on the calling thread;
+ *   - the caller owns every host buffer; the engine owns its device memory; one engine per device;
+ *     calls on one engine are serialized by the caller (the reference is single-threaded too);
+ *   - no callbacks; safe to call with the Python GIL released (ctypes default);
+ *   - token buffers are int32 row-major; logits are fp32 row-major;
+ *   - "*_device" entry points take pointers that are already resident in HBM on the engine's
+ *     device and run on the engine's stream (pg_engine_set_stream).
+ */
+#ifndef PGIBBS_H
+#define PGIBBS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_ERR_INVALID 1   /* bad argument / shape */
+#define PG_ERR_HIP 2       /* HIP runtime failure (message has hipGetErrorString) */
+#define PG_ERR_NO_DEVICE 3 /* no MI355X visible -- the product never falls back to a CPU path */
+#define PG_ERR_WEIGHTS 4   /* missing / mis-shaped tensor in the state dict */
+#define PG_ERR_UNSUPPORTED 5
+
+const char* pg_version(void);
+const char* pg_last_error(void);
+/* number of HIP devices visible (0 when there is none or the runtime cannot initialise) */
+int pg_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Host: CPython-exact Mersenne Twister.
+ * Replaces the reference's use of the *global* Python RNG on the hot path:
+ *   random.sample(indexes, num_positions)   src/pgen/esm_sampler.py:245, esm_msa_sampler.py:277
+ *   random.choices(seed_seq, k=batch_size)  src/pgen/esm_sampler.py:112
+ *   random.shuffle(positions)               src/pgen/esm_msa_sampler.py:129
+ * The Python layer moves random.getstate() in, generates the whole position table natively, and
+ * moves the advanced state back with random.setstate(), so position selection is bit-exact and
+ * the interpreter's RNG is left exactly where the reference would have left it.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pg_pyrandom pg_pyrandom;
+pg_pyrandom* pg_pyrandom_create(void);
+void pg_pyrandom_destroy(pg_pyrandom*);
+/* random.seed(int): key = little-endian 32-bit words of abs(n) (at least one word) */
+int pg_pyrandom_seed(pg_pyrandom*, const uint32_t* key_words, int n_words);
+int pg_pyrandom_setstate(pg_pyrandom*, const uint32_t* mt624, int index);
+int pg_pyrandom_getstate(const pg_pyrandom*, uint32_t* mt624, int* index);
+uint32_t pg_pyrandom_getrandbits32(pg_pyrandom*, int k /* 1..32 */);
+double pg_pyrandom_random(pg_pyrandom*);
+/* random.sample(population, k): out[k] = chosen population values */
+int pg_pyrandom_sample(pg_pyrandom*, const int32_t* population, int n, int k, int32_t* out);
+/* n_rows successive random.sample calls (one per chain / MSA row), out[n_rows][k] */
+int pg_pyrandom_sample_table(pg_pyrandom*, const int32_t* population, int n, int k, int64_t n_rows, int32_t* out);
+int pg_pyrandom_shuffle(pg_pyrandom*, int32_t* x, int n);
+/* random.choices(range(n), k=k) (no weights): out[k] = chosen indices */
+int pg_pyrandom_choices(pg_pyrandom*, int n, int k, int32_t* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine: holds the weights of one masked LM on one MI355X and runs the Gibbs hot path.
+ * Replaces the `model.model` attribute of the reference's plug-in object
+ * (src/pgen/models.py:59-88; call sites esm_sampler.py:223, esm_msa_sampler.py:136,236) plus the
+ * per-position Python loop around it (esm_sampler.py:209-234, esm_msa_sampler.py:128-145,221-248).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pg_engine pg_engine;
+
+#define PG_ARCH_ESM1B 1 /* fair-esm ProteinBertModel, "ESM-1b" architecture (ESM-1b, ESM-1v) */
+#define PG_ARCH_MSA1B 2 /* fair-esm MSATransformer (esm_msa1b_t12_100M_UR50S) */
+
+#define PG_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream (throughput mode) */
+#define PG_PREC_FP32 1 /* fp32 MFMA operands and accumulate (parity mode, 1/16 of the bf16 MFMA rate) */
+
+typedef struct {
+  int32_t arch;
+  int32_t vocab;         /* 33 */
+  int32_t d_model;       /* 1280 (ESM-1b) / 768 (MSA-1b); multiple of 128 */
+  int32_t n_layers;      /* 33 / 12 */
+  int32_t n_heads;       /* d_model / 64: head dim is 64 in both models */
+  int32_t d_ffn;         /* 5120 / 3072; multiple of 128 */
+  int32_t max_positions; /* learned position table has max_positions + pad_idx + 1 rows */
+  int32_t pad_idx, mask_idx, cls_idx, eos_idx;
+  int32_t token_dropout; /* 1 for ESM-1b, 0 for MSA-1b */
+  int32_t max_msa_rows;  /* rows of msa_position_embedding (1024), 0 for ESM-1b */
+  float layer_norm_eps;  /* 1e-5 */
+} pg_model_config;
+
+/* one fp32 tensor of a fair-esm state dict, by its fair-esm key */
+typedef struct {
+  const char* name;
+  const float* data;
+  int64_t numel;
+} pg_tensor;
+
+int pg_engine_create(const pg_model_config* cfg, const pg_tensor* tensors, int n_tensors, int device_ordinal,
+                     int precision, pg_engine** out);
+void pg_engine_destroy(pg_engine*);
+/* run on a caller-provided hipStream_t (NULL = the engine's own stream) */
+int pg_engine_set_stream(pg_engine*, void* hip_stream);
+int pg_engine_synchronize(pg_engine*);
+int pg_engine_device(const pg_engine*);
+
+/* Sampling parameters == the kwargs of generate() that reach generate_step
+ * (src/pgen/esm_sampler.py:8-45, 227-232). */
+typedef struct {
+  int32_t mask;        /* scatter <mask> at the targets before the forward (esm_sampler.py:220-221) */
+  int32_t mask_idx;    /* alphabet.mask_idx */
+  int32_t top_k;       /* as passed by the caller; the sample/top_k rule of :32-38 is applied inside */
+  int32_t burnin;      /* iterations ii < burnin draw from the full distribution; INT32_MAX = inf */
+  float temperature;   /* NaN == None (no division) */
+  int32_t n_valid;     /* <= 32 */
+  int32_t valid_idx[32]; /* sampler.valid_aa_idx (esm_sampler.py:82, esm_msa_sampler.py:65) */
+  uint64_t rng_seed;   /* pg_draw v1 Philox key */
+  uint32_t rng_stream; /* Philox counter word 3 */
+  uint32_t row_id_base;/* global id of row 0 (Philox counter word 0 = row_id_base + row): results are
+                          identical for any sharding of the chains over GPUs */
+  int32_t iter_base;   /* Philox counter word 1 = iter_base + iteration */
+} pg_sample_params;
+
+/* ---- ESM-1b -------------------------------------------------------------------------------
+ * pg_esm_forward_logits: model.model(tokens)["logits"] (esm_sampler.py:223): tokens[B,T] -> logits[B,T,V].
+ * pg_esm_gibbs_run: the whole `for ii in range(num_iters)` loop of ESM_sampler.generate
+ *   (esm_sampler.py:209-234) for one batch: per iteration mask scatter -> forward -> restrict /
+ *   temperature / top-k / categorical -> write-back, all on the device with no host round trip.
+ *   target_idx[n_iters][B][P] are the (1-based token) positions chosen on the host; entries < 0 are
+ *   skipped (ragged lists); bit 30 set = position already written by a later duplicate in the same
+ *   row (sampled but not written back: keeps the reference's sequential last-write-wins result).
+ *   Optional outputs (NULL to skip): sampled_logits[n_iters][B][P][V], sampled_tokens[n_iters][B][P].
+ */
+int pg_esm_forward_logits(pg_engine*, const int32_t* tokens, int B, int T, float* logits_out);
+int pg_esm_gibbs_run(pg_engine*, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,
+                     const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
+/* same, every pointer device-resident (tokens stay in HBM; used by bench.py and multi-GPU drivers) */
+int pg_esm_gibbs_run_device(pg_engine*, int32_t* d_tokens_inout, int B, int T, const int32_t* d_target_idx,
+                            int n_iters, int P, const pg_sample_params* params, float* d_sampled_logits,
+                            int32_t* d_sampled_tokens);
+
+/* ---- ESM-MSA-1b ---------------------------------------------------------------------------
+ * tokens[B][R][C] (C = L + 1: <cls> then L columns, no <eos>).
+ * pg_msa_gibbs_run: loop of ESM_MSA_sampler.generate (esm_msa_sampler.py:221-248):
+ *   target_idx[n_iters][B][R][P].
+ * pg_msa_gibbs_single_run: loop of ESM_MSA_sampler.generate_single (esm_msa_sampler.py:128-145), B = 1:
+ *   n_steps forwards; step s masks row `mask_row` and samples row `target_row` at
+ *   step_idx[s][P_max] (entries < 0 = padding of the shorter partitions); sample flag per step.
+ */
+int pg_msa_forward_logits(pg_engine*, const int32_t* tokens, int B, int R, int C, float* logits_out);
+int pg_msa_gibbs_run(pg_engine*, int32_t* tokens_inout, int B, int R, int C, const int32_t* target_idx, int n_iters,
+                     int P, const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
+int pg_msa_gibbs_single_run(pg_engine*, int32_t* tokens_inout, int R, int C, int mask_row, int target_row,
+                            const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
+                            const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
+
+/* ---- stand-alone data-parallel ends of the iteration --------------------------------------
+ * For plug-in models whose forward is not this engine (the reference accepts any object with
+ * .model/.alphabet/.batch_converter, esm_sampler.py:54-58): logits come from the caller's model,
+ * mask scatter and the draw run here.  All pointers device-resident; `stream` is a hipStream_t.
+ *   tokens[n_rows][width] int32; idx[n_sel][P]; row_map[n_sel] (NULL: row r = r) maps a selected row to
+ *   its token row; logits[n_rows][width][V] fp32 (full model output).
+ * pg_mask_scatter_device  == mask_target_indexes      (esm_sampler.py:259-262, esm_msa_sampler.py:255-264)
+ * pg_sample_writeback_device == generate_step + write (esm_sampler.py:225-234)
+ */
+int pg_mask_scatter_device(void* stream, int32_t* d_tokens, int64_t n_rows, int width, const int32_t* d_idx,
+                           const int32_t* d_row_map, int64_t n_sel, int P, int mask_idx);
+int pg_sample_writeback_device(void* stream, int32_t* d_tokens, int64_t n_rows, int width, const float* d_logits,
+                               int V, const int32_t* d_idx, const int32_t* d_row_map, int64_t n_sel, int P,
+                               const pg_sample_params* params, int iteration, int32_t* d_sampled_tokens);
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * HIP-event timing of kernel classes on the engine's stream (bench.py's roofline figure).
+ * class names: "gemm", "attention", "layernorm", "embed", "head", "sample".  */
+int pg_prof_enable(pg_engine*, int on);
+int pg_prof_reset(pg_engine*);
+int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t* launches);
+
+/* ---- kernel-level debug entry points (parity tests call individual kernels through these) --- */
+/* out[M][N] = x[M][K] @ w[N][K]^T + bias (fp32 host buffers; computed in `precision`); epi: 0 none, 1 gelu */
+int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
+                int K, int epi);
+/* y = LayerNorm(x[M][d]) * gamma + beta */
+int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d,
+                     float eps);
+/* softmax(q k^T) v per (b, h); q already scaled; qkv[B][T][3*H*64] fp32 -> ctx[B][T][H*64] */
+int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, int B, int T, int H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGIBBS_H */

@@ -1,0 +1,111 @@
+"""Token tables and batch converters of the ESM-1b / ESM-MSA-1b model families.
+
+The reference gets these from fair-esm (`esm.data.Alphabet`, `BatchConverter`) through its model
+wrappers (/root/reference/src/pgen/models.py:59-88) and patches the MSA converter so that a literal
+"<mask>" in a seed string counts as one column (models.py:6-56).  fair-esm is not a dependency of
+this package; the tables are restated from its published vocabulary and pinned by
+the reference's own tokenisation tests (test_esm_msa_sampler.py:43-84: <cls>=0, A=5, C=23, D=13,
+E=9, B=25, <mask>=32).
+"""
+import re
+
+import torch
+
+PROTEINSEQ_TOKS = list("LAGVSERTIDPKQNFYMHWCXBUZO.-")
+_TOKEN_RE = re.compile(r"<[a-z_0-9]+>|.")
+
+
+class Alphabet:
+    """"ESM-1b" style alphabet: <cls> <pad> <eos> <unk> + 27 residues/gap symbols + <null_1> + <mask>."""
+
+    def __init__(self, prepend_bos=True, append_eos=True):
+        self.standard_toks = list(PROTEINSEQ_TOKS)
+        self.prepend_toks = ["<cls>", "<pad>", "<eos>", "<unk>"]
+        self.append_toks = ["<mask>"]
+        self.all_toks = list(self.prepend_toks) + list(self.standard_toks)
+        while len(self.all_toks) % 8:
+            self.all_toks.append("<null_%d>" % (8 - len(self.all_toks) % 8))
+        self.all_toks += self.append_toks
+        self.tok_to_idx = {t: i for i, t in enumerate(self.all_toks)}
+        self.unk_idx = self.tok_to_idx["<unk>"]
+        self.padding_idx = self.tok_to_idx["<pad>"]
+        self.cls_idx = self.tok_to_idx["<cls>"]
+        self.mask_idx = self.tok_to_idx["<mask>"]
+        self.eos_idx = self.tok_to_idx["<eos>"]
+        self.prepend_bos = prepend_bos
+        self.append_eos = append_eos
+
+    def __len__(self):
+        return len(self.all_toks)
+
+    def get_idx(self, tok):
+        return self.tok_to_idx.get(tok, self.unk_idx)
+
+    def get_tok(self, ind):
+        return self.all_toks[int(ind)]
+
+    def to_dict(self):
+        return dict(self.tok_to_idx)
+
+    def tokenize(self, text):
+        return _TOKEN_RE.findall(text)
+
+    def encode(self, text):
+        return [self.get_idx(t) for t in self.tokenize(text)]
+
+    def get_batch_converter(self, msa=False):
+        return MSABatchConverter(self) if msa else BatchConverter(self)
+
+
+def rawbatchlen(raw):
+    """Number of tokens in a string where <...> counts as one (models.py:6-16)."""
+    return len(_TOKEN_RE.findall(raw))
+
+
+class BatchConverter:
+    """list[(label, str)] -> (labels, strs, int64 tokens [B, maxlen + bos + eos]) padded with <pad>."""
+
+    def __init__(self, alphabet):
+        self.alphabet = alphabet
+
+    def __call__(self, raw_batch):
+        a = self.alphabet
+        labels, strs = [l for l, _ in raw_batch], [s for _, s in raw_batch]
+        enc = [a.encode(s) for s in strs]
+        max_len = max((len(e) for e in enc), default=0)
+        tokens = torch.full((len(raw_batch), max_len + int(a.prepend_bos) + int(a.append_eos)), a.padding_idx,
+                            dtype=torch.int64)
+        for i, e in enumerate(enc):
+            if a.prepend_bos:
+                tokens[i, 0] = a.cls_idx
+            if e:
+                tokens[i, int(a.prepend_bos):len(e) + int(a.prepend_bos)] = torch.tensor(e, dtype=torch.int64)
+            if a.append_eos:
+                tokens[i, len(e) + int(a.prepend_bos)] = a.eos_idx
+        return labels, strs, tokens
+
+
+class MSABatchConverter(BatchConverter):
+    """One MSA (list of (label, str)) or a list of MSAs -> int64 [B, R, C]; ragged rows raise
+    RuntimeError exactly as in models.py:44-49."""
+
+    def __call__(self, inputs):
+        if isinstance(inputs[0][0], str):
+            raw_batch = [inputs]
+        else:
+            raw_batch = inputs
+        a = self.alphabet
+        batch_size = len(raw_batch)
+        max_alignments = max(len(msa) for msa in raw_batch)
+        max_seqlen = max(rawbatchlen(msa[0][1]) for msa in raw_batch)
+        tokens = torch.full((batch_size, max_alignments, max_seqlen + int(a.prepend_bos) + int(a.append_eos)),
+                            a.padding_idx, dtype=torch.int64)
+        labels, strs = [], []
+        for i, msa in enumerate(raw_batch):
+            if len(set(rawbatchlen(seq) for _, seq in msa)) != 1:
+                raise RuntimeError("Received unaligned sequences for input to MSA, all sequence lengths must be equal.")
+            msa_labels, msa_strs, msa_tokens = super().__call__(msa)
+            labels.append(msa_labels)
+            strs.append(msa_strs)
+            tokens[i, :msa_tokens.size(0), :msa_tokens.size(1)] = msa_tokens
+        return labels, strs, tokens

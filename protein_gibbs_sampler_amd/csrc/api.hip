@@ -1,0 +1,302 @@
+// extern "C" surface declared in include/pgibbs.h.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "engine.h"
+
+namespace pg {
+const char* last_error_cstr();
+}
+using namespace pg;
+
+namespace {
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (dev >= 0 && dev != prev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int check_params(const pg_sample_params* p) {
+  if (!p) return fail(PG_ERR_INVALID, "null pg_sample_params");
+  if (p->n_valid < 1 || p->n_valid > 32) return fail(PG_ERR_INVALID, "n_valid must be in 1..32");
+  return PG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* pg_version(void) { return "pgibbs 0.1 (gfx950)"; }
+const char* pg_last_error(void) { return last_error_cstr(); }
+
+int pg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pg_engine_create(const pg_model_config* cfg, const pg_tensor* tensors, int n_tensors, int device_ordinal,
+                     int precision, pg_engine** out) {
+  if (!cfg || !out || (n_tensors > 0 && !tensors)) return fail(PG_ERR_INVALID, "pg_engine_create: null argument");
+  *out = nullptr;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  pg_engine* h = new pg_engine;
+  int rc = h->e.init(cfg, tensors, n_tensors, device_ordinal, precision);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc != PG_OK) {
+    std::string keep = pg_last_error();
+    delete h;
+    set_error(keep);
+    return rc;
+  }
+  *out = h;
+  return PG_OK;
+}
+
+void pg_engine_destroy(pg_engine* h) { delete h; }
+
+int pg_engine_set_stream(pg_engine* h, void* hip_stream) {
+  if (!h) return fail(PG_ERR_INVALID, "null engine");
+  h->e.stream = hip_stream ? (hipStream_t)hip_stream : h->e.own_stream;
+  return PG_OK;
+}
+int pg_engine_synchronize(pg_engine* h) {
+  if (!h) return fail(PG_ERR_INVALID, "null engine");
+  DeviceGuard g(h->e.device);
+  PG_HIP(hipStreamSynchronize(h->e.stream));
+  return PG_OK;
+}
+int pg_engine_device(const pg_engine* h) { return h ? h->e.device : -1; }
+
+// ---- ESM-1b ---------------------------------------------------------------------------------
+int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, float* logits_out) {
+  if (!h || !tokens || !logits_out) return fail(PG_ERR_INVALID, "pg_esm_forward_logits: null argument");
+  Engine& e = h->e;
+  if (e.cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
+  if (B < 0 || T < 1) return fail(PG_ERR_INVALID, "bad shape");
+  if (T > e.cfg.max_positions + 2) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
+  if (B == 0) return PG_OK;
+  DeviceGuard g(e.device);
+  const int64_t M = (int64_t)B * T;
+  int rc;
+  if ((rc = e.d_tokens.ensure((size_t)M * 4, e.stream))) return rc;
+  if ((rc = e.logits.ensure((size_t)M * e.cfg.vocab * 4, e.stream))) return rc;
+  PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens, (size_t)M * 4, hipMemcpyHostToDevice, e.stream));
+  if ((rc = e.esm_trunk(e.d_tokens.as<int32_t>(), B, T))) return rc;
+  if ((rc = e.head(nullptr, nullptr, 1, T, M, e.logits.as<float>()))) return rc;
+  PG_HIP(hipMemcpyAsync(logits_out, e.logits.p, (size_t)M * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
+  PG_HIP(hipStreamSynchronize(e.stream));
+  return PG_OK;
+}
+
+int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T, const int32_t* d_target_idx, int n_iters,
+                            int P, const pg_sample_params* params, float* d_sampled_logits, int32_t* d_sampled_tokens) {
+  if (!h || !d_tokens_inout || (!d_target_idx && P > 0 && n_iters > 0))
+    return fail(PG_ERR_INVALID, "pg_esm_gibbs_run_device: null argument");
+  int rc = check_params(params);
+  if (rc) return rc;
+  DeviceGuard g(h->e.device);
+  return h->e.esm_gibbs_device(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
+}
+
+int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,
+                     const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
+  if (!h || !tokens_inout || (!target_idx && P > 0 && n_iters > 0)) return fail(PG_ERR_INVALID, "pg_esm_gibbs_run: null argument");
+  int rc = check_params(params);
+  if (rc) return rc;
+  if (B < 0 || T < 1 || P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "bad shape");
+  if (B == 0) return PG_OK;
+  Engine& e = h->e;
+  DeviceGuard g(e.device);
+  const size_t tok_bytes = (size_t)B * T * 4;
+  const size_t n_draws = (size_t)B * P * n_iters;
+  if ((rc = e.d_tokens.ensure(tok_bytes, e.stream))) return rc;
+  if ((rc = e.d_idx.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
+  if (sampled_logits && (rc = e.d_samp_logits.ensure((n_draws ? n_draws : 1) * e.cfg.vocab * 4, e.stream))) return rc;
+  if (sampled_tokens && (rc = e.d_samp_tok.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
+  PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens_inout, tok_bytes, hipMemcpyHostToDevice, e.stream));
+  if (n_draws) PG_HIP(hipMemcpyAsync(e.d_idx.p, target_idx, n_draws * 4, hipMemcpyHostToDevice, e.stream));
+  rc = e.esm_gibbs_device(e.d_tokens.as<int32_t>(), B, T, e.d_idx.as<int32_t>(), n_iters, P, params,
+                          sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
+                          sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
+  if (rc) return rc;
+  PG_HIP(hipMemcpyAsync(tokens_inout, e.d_tokens.p, tok_bytes, hipMemcpyDeviceToHost, e.stream));
+  if (sampled_logits && n_draws)
+    PG_HIP(hipMemcpyAsync(sampled_logits, e.d_samp_logits.p, n_draws * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
+  if (sampled_tokens && n_draws)
+    PG_HIP(hipMemcpyAsync(sampled_tokens, e.d_samp_tok.p, n_draws * 4, hipMemcpyDeviceToHost, e.stream));
+  PG_HIP(hipStreamSynchronize(e.stream));
+  return PG_OK;
+}
+
+// ---- ESM-MSA-1b (kernels land in a later milestone of this round) ---------------------------------
+int pg_msa_forward_logits(pg_engine* h, const int32_t*, int, int, int, float*) {
+  (void)h;
+  return fail(PG_ERR_UNSUPPORTED, "MSA-1b forward is not implemented in this build");
+}
+int pg_msa_gibbs_run(pg_engine* h, int32_t*, int, int, int, const int32_t*, int, int, const pg_sample_params*, float*,
+                     int32_t*) {
+  (void)h;
+  return fail(PG_ERR_UNSUPPORTED, "MSA-1b Gibbs loop is not implemented in this build");
+}
+int pg_msa_gibbs_single_run(pg_engine* h, int32_t*, int, int, int, int, const int32_t*, const int32_t*, int, int,
+                            const pg_sample_params*, float*, int32_t*) {
+  (void)h;
+  return fail(PG_ERR_UNSUPPORTED, "MSA-1b single-row Gibbs loop is not implemented in this build");
+}
+
+// ---- stand-alone ends of the iteration ---------------------------------------------------------
+int pg_mask_scatter_device(void* stream, int32_t* d_tokens, int64_t n_rows, int width, const int32_t* d_idx,
+                           const int32_t* d_row_map, int64_t n_sel, int P, int mask_idx) {
+  if (!d_tokens || (!d_idx && n_sel * P > 0)) return fail(PG_ERR_INVALID, "pg_mask_scatter_device: null argument");
+  if (n_rows < 0 || width < 1 || n_sel < 0 || P < 0) return fail(PG_ERR_INVALID, "bad shape");
+  return launch_mask_scatter((hipStream_t)stream, d_tokens, width, d_idx, d_row_map, n_sel, P, mask_idx);
+}
+
+int pg_sample_writeback_device(void* stream, int32_t* d_tokens, int64_t n_rows, int width, const float* d_logits, int V,
+                               const int32_t* d_idx, const int32_t* d_row_map, int64_t n_sel, int P,
+                               const pg_sample_params* params, int iteration, int32_t* d_sampled_tokens) {
+  if (!d_tokens || !d_logits || (!d_idx && n_sel * P > 0)) return fail(PG_ERR_INVALID, "pg_sample_writeback_device: null argument");
+  int rc = check_params(params);
+  if (rc) return rc;
+  if (n_rows < 0 || width < 1 || n_sel < 0 || P < 0 || V < 1) return fail(PG_ERR_INVALID, "bad shape");
+  return launch_sample_writeback((hipStream_t)stream, d_tokens, width, d_logits, V, 0, d_idx, d_row_map, n_sel, P, params,
+                                 iteration, d_sampled_tokens);
+}
+
+// ---- measurement ----------------------------------------------------------------------------
+int pg_prof_enable(pg_engine* h, int on) {
+  if (!h) return fail(PG_ERR_INVALID, "null engine");
+  h->e.prof.on = on != 0;
+  return PG_OK;
+}
+int pg_prof_reset(pg_engine* h) {
+  if (!h) return fail(PG_ERR_INVALID, "null engine");
+  DeviceGuard g(h->e.device);
+  PG_HIP(hipStreamSynchronize(h->e.stream));
+  h->e.prof.reset();
+  return PG_OK;
+}
+int pg_prof_get(pg_engine* h, const char* kernel_class, double* total_ms, int64_t* launches) {
+  if (!h || !kernel_class || !total_ms || !launches) return fail(PG_ERR_INVALID, "pg_prof_get: null argument");
+  static const char* names[PC_COUNT] = {"gemm", "attention", "layernorm", "embed", "head", "sample"};
+  int cls = -1;
+  for (int i = 0; i < PC_COUNT; ++i)
+    if (!strcmp(names[i], kernel_class)) cls = i;
+  if (cls < 0) return fail(PG_ERR_INVALID, std::string("unknown kernel class ") + kernel_class);
+  DeviceGuard g(h->e.device);
+  PG_HIP(hipStreamSynchronize(h->e.stream));
+  double ms = 0;
+  int64_t n = 0;
+  for (auto& r : h->e.prof.recs)
+    if (r.cls == cls) {
+      float t = 0;
+      PG_HIP(hipEventElapsedTime(&t, r.a, r.b));
+      ms += t;
+      ++n;
+    }
+  *total_ms = ms;
+  *launches = n;
+  return PG_OK;
+}
+
+// ---- kernel-level debug entry points ------------------------------------------------------------
+namespace {
+struct Tmp {
+  std::vector<void*> v;
+  ~Tmp() { for (void* p : v) (void)hipFree(p); }
+  void* get(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, bytes ? bytes : 4);
+    v.push_back(p);
+    return p;
+  }
+};
+int dbg_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(PG_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n) return fail(PG_ERR_INVALID, "bad device ordinal");
+  PG_HIP(hipSetDevice(device));
+  return PG_OK;
+}
+}  // namespace
+
+int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
+                int K, int epi) {
+  if (precision != PG_PREC_BF16) return fail(PG_ERR_UNSUPPORTED, "only bf16");
+  if (!x || !w || !bias || !out || M < 1 || N % 128 || K % 64) return fail(PG_ERR_INVALID, "pg_dbg_gemm: bad argument");
+  DeviceGuard g(-1);
+  int rc = dbg_device(device);
+  if (rc) return rc;
+  const int Mp = round_up(M, kRowPad);
+  Tmp t;
+  float* dx = (float*)t.get((size_t)Mp * K * 4);
+  float* dw = (float*)t.get((size_t)N * K * 4);
+  float* db = (float*)t.get((size_t)N * 4);
+  float* dout = (float*)t.get((size_t)Mp * N * 4);
+  bf16_t* bx = (bf16_t*)t.get((size_t)Mp * K * 2);
+  bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2);
+  if (!dx || !dw || !db || !dout || !bx || !bw) return fail(PG_ERR_HIP, "hipMalloc failed");
+  PG_HIP(hipMemcpy(dx, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(dw, w, (size_t)N * K * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, dx, bx, (int64_t)Mp * K, 1.f))) return rc;
+  if ((rc = launch_f32_to_bf16(nullptr, dw, bw, (int64_t)N * K, 1.f))) return rc;
+  if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, Mp, N, K, K, K, N, epi ? EPI_F32_GELU : EPI_F32))) return rc;
+  PG_HIP(hipDeviceSynchronize());
+  PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  return PG_OK;
+}
+
+int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps) {
+  if (!x || !gamma || !beta || !y || M < 1 || d < 4) return fail(PG_ERR_INVALID, "pg_dbg_layernorm: bad argument");
+  DeviceGuard g(-1);
+  int rc = dbg_device(device);
+  if (rc) return rc;
+  Tmp t;
+  float* dx = (float*)t.get((size_t)M * d * 4);
+  float* dg = (float*)t.get((size_t)d * 4);
+  float* dbt = (float*)t.get((size_t)d * 4);
+  float* dy = (float*)t.get((size_t)M * d * 4);
+  if (!dx || !dg || !dbt || !dy) return fail(PG_ERR_HIP, "hipMalloc failed");
+  PG_HIP(hipMemcpy(dx, x, (size_t)M * d * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(dg, gamma, (size_t)d * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(dbt, beta, (size_t)d * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_layernorm_f32(nullptr, dx, dg, dbt, dy, M, d, eps))) return rc;
+  PG_HIP(hipDeviceSynchronize());
+  PG_HIP(hipMemcpy(y, dy, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+  return PG_OK;
+}
+
+int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, int B, int T, int H) {
+  if (precision != PG_PREC_BF16) return fail(PG_ERR_UNSUPPORTED, "only bf16");
+  if (!qkv || !ctx || B < 1 || T < 1 || H < 1) return fail(PG_ERR_INVALID, "pg_dbg_attention: bad argument");
+  DeviceGuard g(-1);
+  int rc = dbg_device(device);
+  if (rc) return rc;
+  const int d = H * 64;
+  const int64_t M = (int64_t)B * T;
+  Tmp t;
+  float* dq = (float*)t.get((size_t)M * 3 * d * 4);
+  bf16_t* bq = (bf16_t*)t.get((size_t)M * 3 * d * 2);
+  bf16_t* bc = (bf16_t*)t.get((size_t)M * d * 2);
+  float* dc = (float*)t.get((size_t)M * d * 4);
+  if (!dq || !bq || !bc || !dc) return fail(PG_ERR_HIP, "hipMalloc failed");
+  PG_HIP(hipMemcpy(dq, qkv, (size_t)M * 3 * d * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
+  if ((rc = launch_attention_bf16(nullptr, bq, bc, B, T, H, 3 * d, d, d, 2 * d))) return rc;
+  if ((rc = launch_bf16_to_f32(nullptr, bc, dc, M * d))) return rc;
+  PG_HIP(hipDeviceSynchronize());
+  PG_HIP(hipMemcpy(ctx, dc, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+  return PG_OK;
+}
+
+}  // extern "C"

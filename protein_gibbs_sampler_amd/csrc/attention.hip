@@ -1,0 +1,165 @@
+// Fused multi-head self-attention for one sequence per workgroup (ESM-1b layers):
+//   ctx[b, t, h*64:(h+1)*64] = softmax_j( q[b,t,h] . k[b,j,h] ) @ v[b,:,h]        (q pre-scaled by 64^-0.5)
+// This is the attention inside fair-esm's ProteinBertModel that the reference reaches through
+// `self.model.model(batch)["logits"]` (/root/reference/src/pgen/esm_sampler.py:223).
+//
+// CDNA4 mapping (head dim is 64 in ESM-1b and MSA-1b):
+//   * grid = B*H workgroups of 4 waves; K (row-major, XOR-swizzled 16-B chunks) and V^T live in LDS for
+//     the whole sequence (T <= 576: 72 KB + 74 KB) and are shared by all query blocks.
+//   * per wave, 16 queries at a time: S^T = K.Q^T with v_mfma_f32_16x16x32_bf16 ("swapped" product), so a
+//     lane holds, for ONE query (lane & 15), 4 consecutive keys of every 16-key block: the whole score
+//     row is lane-local except for a 4-lane (xor 16, 32) shuffle reduction -> exact (non-online) softmax
+//     in registers, no LDS round trip for P.
+//   * the K-slot order of the PV contraction is free, so it is chosen to be exactly the order the lane
+//     already holds P in (two 16-key blocks per 32-wide MFMA step); V^T rows in LDS then supply the
+//     matching 4+4 contiguous keys per lane with two conflict-free ds_read_b64.
+//   * O^T = V^T.P^T, so a lane ends with 4 consecutive d for one query -> 8-byte row-major stores.
+#include "kernels.h"
+
+namespace pg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// MAXKB = number of 16-key blocks computed (T <= 16*MAXKB), even.  The dispatch ladder guarantees
+// T > 16*(MAXKB-6), so only the last 6 blocks can hold masked (>= T) keys.
+template <int MAXKB>
+__global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
+                                                       int H, int ld_qkv, int ld_ctx, int k_off, int v_off) {
+  constexpr int VT_LD = MAXKB * 16 + 8;  // bf16 elements per V^T row (592 B at MAXKB=18: conflict-free b64 reads)
+  __shared__ __attribute__((aligned(16))) char smem[MAXKB * 16 * 128 + 64 * VT_LD * 2];
+  char* Ks = smem;
+  bf16_t* Vt = (bf16_t*)(smem + MAXKB * 16 * 128);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const bf16_t* base = qkv + (size_t)b * T * ld_qkv + h * 64;
+  // All MAXKB key blocks are computed unconditionally: K rows / V^T columns past T are zero-filled and
+  // their scores are masked, so no wave-uniform branches (and no dynamic register indexing) are needed.
+  constexpr int nkb = MAXKB;
+  constexpr int nkc = MAXKB / 2;
+  constexpr int tpad = MAXKB * 16;
+
+  // ---- stage K (swizzled rows) ------------------------------------------------------------
+  for (int i = tid; i < nkb * 16 * 8; i += 256) {
+    const int row = i >> 3, c = i & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < T) v = *(const uint4*)(base + (size_t)row * ld_qkv + k_off + c * 8);
+    *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+  }
+  // ---- stage V^T: lane <-> key, so transposed 2-byte LDS writes are bank-conflict free -------
+  for (int i = tid; i < tpad * 8; i += 256) {
+    const int key = i % tpad, c = i / tpad;   // tpad is a multiple of 32; a wave covers 64 keys of one chunk
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (key < T) v = *(const uint4*)(base + (size_t)key * ld_qkv + v_off + c * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VT_LD + key] = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nqb = (T + 15) >> 4;  // query blocks of 16
+  for (int qb = wave; qb < nqb; qb += 4) {
+    // Q fragment (MFMA B operand): query fr, d = kk*32 + fq*8 .. +7
+    int qrow = qb * 16 + fr;
+    if (qrow >= T) qrow = T - 1;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
+
+    // S^T blocks: st[kb][r] = S[query fr][key kb*16 + fq*4 + r]
+    f32x4 st[MAXKB];
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+      st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int krow = kb * 16 + fr;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+      }
+    }
+    // exact softmax over keys (lane-local + 4-lane reduction)
+    float mx = -3.0e38f;
+    int tl = T - fq * 4;                      // key kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
+    asm volatile("" : "+v"(tl));              // keep the compares inside the loop (no hoisted lane masks)
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kb >= MAXKB - 6 && kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
+        mx = fmaxf(mx, st[kb][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(st[kb][r] - mx);
+        st[kb][r] = e;
+        sum += e;
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    // O^T[d][q] = sum_key V^T[d][key] * P^T[key][q]; K-slot (fq*8 + j) of chunk c <-> key (2c + (j>>2))*16 + fq*4 + (j&3)
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < nkc; ++c) {
+      union { bf16x8 v; uint32_t u[4]; } pf;
+      const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
+      pf.u[0] = pack_bf16x2(lo[0] * inv, lo[1] * inv);
+      pf.u[1] = pack_bf16x2(lo[2] * inv, lo[3] * inv);
+      pf.u[2] = pack_bf16x2(hi[0] * inv, hi[1] * inv);
+      pf.u[3] = pack_bf16x2(hi[2] * inv, hi[3] * inv);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        union { bf16x8 v; uint2 h[2]; } vf;
+        const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
+        vf.h[0] = *(const uint2*)(vrow);
+        vf.h[1] = *(const uint2*)(vrow + 16);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+      }
+    }
+    // store: lane holds O[q = qb*16 + fr][d = db*16 + fq*4 + r]
+    const int q = qb * 16 + fr;
+    if (q < T) {
+      bf16_t* dst = ctx + ((size_t)b * T + q) * ld_ctx + h * 64 + fq * 4;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        uint2 p;
+        p.x = pack_bf16x2(o[db][0], o[db][1]);
+        p.y = pack_bf16x2(o[db][2], o[db][3]);
+        *(uint2*)(dst + db * 16) = p;
+      }
+    }
+  }
+}
+
+int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
+                          int k_off, int v_off) {
+  if (B == 0) return 0;
+  dim3 grid((unsigned)(B * H)), block(256);
+#define PG_ATT(KB)                                                                                             \
+  else if (T <= KB * 16) {                                                                                     \
+    hipLaunchKernelGGL(attention_kernel<KB>, grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off); \
+  }
+  if (T <= 0) return fail(1, "attention: empty sequence");
+  PG_ATT(2) PG_ATT(4) PG_ATT(8) PG_ATT(12) PG_ATT(18) PG_ATT(24) PG_ATT(30) PG_ATT(36)
+#undef PG_ATT
+  else {
+    return fail(5, "attention: sequences longer than 576 tokens are not supported yet");
+  }
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace pg

@@ -1,0 +1,319 @@
+// Memory-bound kernels of the forward pass (HBM roofline): token embedding + token-dropout rescale +
+// learned positions + LayerNorm, LayerNorm (fp32 residual -> bf16 GEMM operand), gather+LayerNorm of
+// the sampled rows, and the LM-head tail (LayerNorm -> tied decoder -> logits).
+//
+// They restate, for the GPU, steps 1-4, the pre-LN of step 5, and steps 6-7 of the ESM-1b forward
+// (fair-esm ProteinBertModel.forward) that the reference reaches through
+// `self.model.model(batch)["logits"]` (/root/reference/src/pgen/esm_sampler.py:223), and step 1-2/4
+// of MSATransformer.forward (A.3; esm_msa_sampler.py:136,236).
+//
+// Layout rule: one 64-lane wave per token row; a row of d fp32 is read as float4 per lane
+// (16 B x 64 lanes = 1 KiB coalesced per instruction); mean/variance by wave shuffle reductions;
+// nothing goes through LDS.
+#include "kernels.h"
+
+namespace pg {
+
+constexpr int kMaxCh = 8;  // d <= 8 * 256 = 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// normalise the row held in v[] (chunk c = lane + 64*i) in place: (x-mean)/sqrt(var+eps)*g + b
+__device__ __forceinline__ void ln_inplace(float4 (&v)[kMaxCh], int nch4, int lane, int d, float eps,
+                                           const float* __restrict__ gamma, const float* __restrict__ beta) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) {
+      const int c = lane + 64 * i;
+      const float4 g = ((const float4*)gamma)[c], b = ((const float4*)beta)[c];
+      v[i].x = v[i].x * rstd * g.x + b.x;
+      v[i].y = v[i].y * rstd * g.y + b.y;
+      v[i].z = v[i].z * rstd * g.z + b.z;
+      v[i].w = v[i].w * rstd * g.w + b.w;
+    }
+}
+
+__device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane) {
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) {
+      uint2 p;
+      p.x = pack_bf16x2(v[i].x, v[i].y);
+      p.y = pack_bf16x2(v[i].z, v[i].w);
+      ((uint2*)dst)[lane + 64 * i] = p;
+    }
+}
+
+// ---- embedding -------------------------------------------------------------------------------
+// tokens[n_seq][T] -> x[n_seq*T][d] fp32 = LN_before(embed[tok]*scale + pos[...] (+ msa_row_pos[r]))
+// token_dropout (ESM-1b): mask rows zeroed, all rows scaled by 0.88 / (1 - n_mask/src_len) per sequence.
+// rows_per_msa > 0 (MSA-1b): adds msa_pos[seq % rows_per_msa].
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ embed,
+                                                      const float* __restrict__ pos, const float* __restrict__ msa_pos,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ x, int64_t n_tok, int T, int d, int pad_idx,
+                                                      int mask_idx, int token_dropout, int rows_per_msa, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_tok) return;
+  const int64_t seq = row / T;
+  const int t = (int)(row - seq * T);
+  const int32_t* trow = tokens + seq * T;
+  const int tok = trow[t];
+  // per-sequence counts: masks, non-pad tokens, non-pad tokens at or before t
+  int n_mask = 0, n_nonpad = 0, n_before = 0;
+  for (int j = lane; j < T; j += 64) {
+    const int tj = trow[j];
+    n_mask += (tj == mask_idx);
+    n_nonpad += (tj != pad_idx);
+    n_before += (tj != pad_idx) && (j <= t);
+  }
+  n_mask = wave_sum_i(n_mask);
+  n_nonpad = wave_sum_i(n_nonpad);
+  n_before = wave_sum_i(n_before);
+  const bool is_pad = (tok == pad_idx);
+  float scale = 1.0f;
+  if (token_dropout) {
+    scale = (1.0f - 0.15f * 0.8f) / (1.0f - (float)n_mask / (float)n_nonpad);
+    if (tok == mask_idx) scale = 0.0f;
+  }
+  const int p = is_pad ? pad_idx : n_before + pad_idx;
+  const int nch4 = d >> 2;
+  const float4* e4 = (const float4*)(embed + (size_t)tok * d);
+  const float4* p4 = (const float4*)(pos + (size_t)p * d);
+  const float4* r4 = rows_per_msa > 0 ? (const float4*)(msa_pos + (size_t)(seq % rows_per_msa) * d) : nullptr;
+  float4 v[kMaxCh];
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) {
+      const int c = lane + 64 * i;
+      const float4 e = e4[c], q = p4[c];
+      v[i] = make_float4(e.x * scale + q.x, e.y * scale + q.y, e.z * scale + q.z, e.w * scale + q.w);
+      if (r4) {
+        const float4 r = r4[c];
+        v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
+      }
+    }
+  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  float4* o = (float4*)(x + (size_t)row * d);
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) o[lane + 64 * i] = is_pad ? make_float4(0.f, 0.f, 0.f, 0.f) : v[i];
+}
+
+// ---- LayerNorm: x fp32 [M][d] -> h bf16 [M][d] ------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ h,
+                                                            int64_t M, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch4 = d >> 2;
+  const float4* x4 = (const float4*)(x + (size_t)row * d);
+  float4 v[kMaxCh];
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
+  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  store_row_bf16(h + (size_t)row * d, v, nch4, lane);
+}
+
+// fp32 -> fp32 LayerNorm (debug entry / strict paths)
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y,
+                                                           int64_t M, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch4 = d >> 2;
+  const float4* x4 = (const float4*)(x + (size_t)row * d);
+  float4 v[kMaxCh];
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
+  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  float4* o = (float4*)(y + (size_t)row * d);
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) o[lane + 64 * i] = v[i];
+}
+
+// ---- gather the sampled rows + final LayerNorm -> bf16 (LM-head dense operand) ---------------
+// sel r -> token row row_of(r) * width + idx[r]; idx < 0 (ragged padding) -> row of zeros.
+// row_map == nullptr: selected row s = r / P maps to token row s.
+__global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                            const int32_t* __restrict__ row_map, int P, int width,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16_t* __restrict__ h, int64_t n_sel, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_sel) return;
+  const int nch4 = d >> 2;
+  int pos = idx ? idx[r] : 0;
+  float4 v[kMaxCh];
+  if (pos < 0) {
+#pragma unroll
+    for (int i = 0; i < kMaxCh; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    int64_t src;
+    if (idx) {
+      pos &= 0x3fffffff;
+      const int64_t s = r / P;
+      src = (row_map ? (int64_t)row_map[s] : s) * width + pos;
+    } else {
+      src = r;
+    }
+    const float4* x4 = (const float4*)(x + (size_t)src * d);
+#pragma unroll
+    for (int i = 0; i < kMaxCh; ++i)
+      if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
+    ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  }
+  store_row_bf16(h + (size_t)r * d, v, nch4, lane);
+}
+
+// ---- LM-head tail: logits[r][V] = LN(g[r]) . embed^T + bias ----------------------------------
+// g = gelu(dense(x)) fp32 [n][d] (GEMM epilogue); the 33 x d tied decoder stays L2-resident.
+__global__ __launch_bounds__(256) void lm_tail_kernel(const float* __restrict__ g, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ embed,
+                                                     const float* __restrict__ out_bias, float* __restrict__ logits,
+                                                     int64_t n, int d, int V, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int nch4 = d >> 2;
+  const float4* x4 = (const float4*)(g + (size_t)r * d);
+  float4 v[kMaxCh];
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
+  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  float mine = 0.f;  // lane t keeps logit t (V <= 64)
+  for (int t = 0; t < V; ++t) {
+    const float4* e4 = (const float4*)(embed + (size_t)t * d);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxCh; ++i)
+      if (lane + 64 * i < nch4) {
+        const float4 e = e4[lane + 64 * i];
+        s += (v[i].x * e.x + v[i].y * e.y) + (v[i].z * e.z + v[i].w * e.w);
+      }
+    s = wave_sum(s);
+    if (lane == t) mine = s + out_bias[t];
+  }
+  if (lane < V) logits[(size_t)r * V + lane] = mine;
+}
+
+// ---- fp32 <-> bf16 conversion (weights at load time, debug entries) ---------------------------
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n, float scale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = f32_to_bf16_dev(src[i] * scale);
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = bf16_to_f32(src[i]);
+}
+__global__ void scale_f32_kernel(float* __restrict__ p, int64_t n, float scale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] *= scale;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+static inline unsigned rows_grid(int64_t rows) { return (unsigned)((rows + 3) / 4); }
+
+int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
+                    const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,
+                    int mask_idx, int token_dropout, int rows_per_msa, float eps) {
+  if (d % 4 || d > kMaxCh * 256) return fail(1, "embed: d must be a multiple of 4 and <= 2048");
+  if (n_tok == 0) return 0;
+  hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(n_tok)), dim3(256), 0, s, tokens, embed, pos, msa_pos, gamma, beta, x,
+                     n_tok, T, d, pad_idx, mask_idx, token_dropout, rows_per_msa, eps);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
+                          int d, float eps) {
+  if (d % 4 || d > kMaxCh * 256) return fail(1, "layernorm: d must be a multiple of 4 and <= 2048");
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, M, d, eps);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_layernorm_f32(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t M, int d,
+                         float eps) {
+  if (d % 4 || d > kMaxCh * 256) return fail(1, "layernorm: d must be a multiple of 4 and <= 2048");
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(layernorm_f32_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, y, M, d, eps);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, const int32_t* row_map, int P, int width,
+                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps) {
+  if (n_sel == 0) return 0;
+  hipLaunchKernelGGL(gather_ln_bf16_kernel, dim3(rows_grid(n_sel)), dim3(256), 0, s, x, idx, row_map, P, width, gamma,
+                     beta, h, n_sel, d, eps);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const float* beta, const float* embed,
+                   const float* out_bias, float* logits, int64_t n, int d, int V, float eps) {
+  if (V > 64) return fail(1, "lm_tail: vocab > 64 unsupported");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(lm_tail_kernel, dim3(rows_grid(n)), dim3(256), 0, s, g, gamma, beta, embed, out_bias, logits, n, d, V,
+                     eps);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_f32_to_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t n, float scale) {
+  if (n == 0) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid), dim3(256), 0, s, src, dst, n, scale);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+int launch_bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n) {
+  if (n == 0) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid), dim3(256), 0, s, src, dst, n);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+int launch_scale_f32(hipStream_t s, float* p, int64_t n, float scale) {
+  if (n == 0) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid), dim3(256), 0, s, p, n, scale);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace pg

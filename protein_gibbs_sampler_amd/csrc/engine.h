@@ -1,0 +1,91 @@
+// Engine: weights of one masked protein LM resident on one MI355X + the Gibbs hot loop.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace pg {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  // grow-only; new storage is zero-filled (pad rows must hold finite values)
+  int ensure(size_t need, hipStream_t s);
+  void release();
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Prof {
+  struct Rec { int cls; hipEvent_t a, b; };
+  bool on = false;
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t get();
+  void reset();
+  void destroy();
+};
+
+enum ProfClass { PC_GEMM = 0, PC_ATTN, PC_LN, PC_EMBED, PC_HEAD, PC_SAMPLE, PC_COUNT };
+
+struct DenseW {   // y = x W^T + b ; W bf16 [N][K], b fp32 [N]
+  bf16_t* w = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;
+};
+struct LnW { float* g = nullptr; float* b = nullptr; };
+
+struct EsmLayer {
+  LnW ln1, ln2;
+  DenseW qkv, out, fc1, fc2;
+};
+struct MsaLayer {
+  LnW ln_row, ln_col, ln_ffn;
+  DenseW row_qkv, row_out, col_qkv, col_out, fc1, fc2;
+};
+
+struct Engine {
+  pg_model_config cfg;
+  int device = 0;
+  int precision = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<void*> owned;   // every hipMalloc'd weight block
+
+  // weights
+  float *embed = nullptr, *pos = nullptr, *msa_pos = nullptr;
+  LnW ln_before, ln_after, head_ln;
+  DenseW head_dense;
+  float* head_bias = nullptr;
+  std::vector<EsmLayer> esm_layers;
+  std::vector<MsaLayer> msa_layers;
+
+  // workspace (grow-only)
+  DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
+  Prof prof;
+
+  ~Engine();
+  int init(const pg_model_config* c, const pg_tensor* tensors, int n_tensors, int device_ordinal, int precision);
+
+  // ---- forward pieces (all on `stream`, device pointers) ----
+  int esm_trunk(const int32_t* d_tok, int B, int T);                         // tokens -> x (before ln_after)
+  int head(const int32_t* d_idx, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits);
+  int esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp,
+                       float* d_samp_logits, int32_t* d_samp_tok);
+
+  // timing helper
+  template <typename F> int timed(int cls, F&& f);
+};
+
+// state-dict lookup used by init
+struct TensorMap {
+  std::map<std::string, const pg_tensor*> m;
+  const float* get(const std::string& name, int64_t numel, std::string& err) const;
+};
+
+}  // namespace pg
+
+struct pg_engine {
+  pg::Engine e;
+};

@@ -1,0 +1,302 @@
+// Engine implementation: weight upload (fp32 state dict -> device bf16/fp32), the ESM-1b forward as a
+// chain of gfx950 kernels on one HIP stream, and the device-resident Gibbs loop
+//   mask scatter -> forward -> LM head at the sampled rows -> draw + write-back
+// which replaces the reference's per-iteration Python loop
+// (/root/reference/src/pgen/esm_sampler.py:209-234) with zero host round trips per iteration.
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace pg {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+int DevBuf::ensure(size_t need, hipStream_t s) {
+  if (need <= bytes) return 0;
+  size_t cap = need + need / 8 + 4096;
+  void* np = nullptr;
+  PG_HIP(hipMalloc(&np, cap));
+  PG_HIP(hipMemsetAsync(np, 0, cap, s));
+  if (p) {
+    PG_HIP(hipStreamSynchronize(s));
+    PG_HIP(hipFree(p));
+  }
+  p = np;
+  bytes = cap;
+  return 0;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  bytes = 0;
+}
+
+hipEvent_t Prof::get() {
+  if (used == pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    pool.push_back(e);
+  }
+  return pool[used++];
+}
+void Prof::reset() {
+  recs.clear();
+  used = 0;
+}
+void Prof::destroy() {
+  for (auto e : pool) (void)hipEventDestroy(e);
+  pool.clear();
+  reset();
+}
+
+template <typename F> int Engine::timed(int cls, F&& f) {
+  if (!prof.on) return f();
+  hipEvent_t a = prof.get(), b = prof.get();
+  PG_HIP(hipEventRecord(a, stream));
+  int rc = f();
+  PG_HIP(hipEventRecord(b, stream));
+  prof.recs.push_back({cls, a, b});
+  return rc;
+}
+
+const float* TensorMap::get(const std::string& name, int64_t numel, std::string& err) const {
+  auto it = m.find(name);
+  if (it == m.end()) {
+    err = "missing tensor '" + name + "'";
+    return nullptr;
+  }
+  if (it->second->numel != numel) {
+    err = "tensor '" + name + "' has " + std::to_string(it->second->numel) + " elements, expected " + std::to_string(numel);
+    return nullptr;
+  }
+  return it->second->data;
+}
+
+Engine::~Engine() {
+  if (device >= 0) (void)hipSetDevice(device);
+  for (void* p : owned) (void)hipFree(p);
+  DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
+                    &d_rowmap, &scratch};
+  for (DevBuf* b : bufs) b->release();
+  prof.destroy();
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight upload
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Uploader {
+  Engine* e;
+  const TensorMap* tm;
+  std::string err;
+
+  float* f32(const std::string& name, int64_t numel) {
+    const float* src = tm->get(name, numel, err);
+    if (!src) return nullptr;
+    void* d = nullptr;
+    if (hipMalloc(&d, (size_t)numel * 4) != hipSuccess) { err = "hipMalloc failed for " + name; return nullptr; }
+    e->owned.push_back(d);
+    if (hipMemcpy(d, src, (size_t)numel * 4, hipMemcpyHostToDevice) != hipSuccess) { err = "H2D failed for " + name; return nullptr; }
+    return (float*)d;
+  }
+  // concatenate several [n_i][K] fp32 matrices (each scaled) into one bf16 [sum n_i][K] device matrix + fp32 bias
+  bool dense(DenseW& out, const std::vector<std::string>& prefixes, const std::vector<float>& scales, int n_each, int K) {
+    const int parts = (int)prefixes.size();
+    const int64_t N = (int64_t)n_each * parts;
+    void *dw = nullptr, *db = nullptr, *tmp = nullptr;
+    if (hipMalloc(&dw, (size_t)N * K * 2) != hipSuccess || hipMalloc(&db, (size_t)N * 4) != hipSuccess ||
+        hipMalloc(&tmp, (size_t)n_each * K * 4) != hipSuccess) { err = "hipMalloc failed for " + prefixes[0]; return false; }
+    e->owned.push_back(dw);
+    e->owned.push_back(db);
+    for (int p = 0; p < parts; ++p) {
+      const float* w = tm->get(prefixes[p] + ".weight", (int64_t)n_each * K, err);
+      const float* b = w ? tm->get(prefixes[p] + ".bias", n_each, err) : nullptr;
+      if (!w || !b) { (void)hipFree(tmp); return false; }
+      bool ok = hipMemcpy(tmp, w, (size_t)n_each * K * 4, hipMemcpyHostToDevice) == hipSuccess;
+      ok = ok && launch_f32_to_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * K, (int64_t)n_each * K, scales[p]) == 0;
+      ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
+      ok = ok && hipMemcpy((float*)db + (size_t)p * n_each, b, (size_t)n_each * 4, hipMemcpyHostToDevice) == hipSuccess;
+      if (ok && scales[p] != 1.0f) ok = launch_scale_f32(e->stream, (float*)db + (size_t)p * n_each, n_each, scales[p]) == 0 &&
+                                        hipStreamSynchronize(e->stream) == hipSuccess;
+      if (!ok) { err = "upload failed for " + prefixes[p]; (void)hipFree(tmp); return false; }
+    }
+    (void)hipFree(tmp);
+    out.w = (bf16_t*)dw;
+    out.b = (float*)db;
+    out.N = (int)N;
+    out.K = K;
+    return true;
+  }
+  bool ln(LnW& out, const std::string& prefix, int d) {
+    out.g = f32(prefix + ".weight", d);
+    out.b = out.g ? f32(prefix + ".bias", d) : nullptr;
+    return out.g && out.b;
+  }
+};
+}  // namespace
+
+int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tensors, int device_ordinal, int prec) {
+  cfg = *c;
+  precision = prec;
+  device = -1;
+  if (cfg.arch != PG_ARCH_ESM1B && cfg.arch != PG_ARCH_MSA1B) return fail(PG_ERR_INVALID, "unknown arch");
+  if (prec != PG_PREC_BF16) return fail(PG_ERR_UNSUPPORTED, "only PG_PREC_BF16 is implemented in this build");
+  if (cfg.d_model % 128 || cfg.d_ffn % 128 || cfg.n_heads * 64 != cfg.d_model)
+    return fail(PG_ERR_INVALID, "d_model and d_ffn must be multiples of 128 and head dim must be 64");
+  if (cfg.vocab < 1 || cfg.vocab > 64) return fail(PG_ERR_INVALID, "vocab must be in 1..64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(PG_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU fallback");
+  if (device_ordinal < 0 || device_ordinal >= ndev) return fail(PG_ERR_INVALID, "Invalid cuda device number: cuda:" + std::to_string(device_ordinal));
+  PG_HIP(hipSetDevice(device_ordinal));
+  device = device_ordinal;
+  PG_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+  stream = own_stream;
+
+  TensorMap tm;
+  for (int i = 0; i < n_tensors; ++i)
+    if (tensors[i].name) tm.m[tensors[i].name] = &tensors[i];
+  Uploader up{this, &tm, ""};
+  const int d = cfg.d_model, f = cfg.d_ffn, V = cfg.vocab;
+  const float qs = 0.125f;  // head_dim^-0.5 = 64^-0.5, folded into W_q and b_q (exact in bf16)
+  bool ok = true;
+  ok = ok && (embed = up.f32("embed_tokens.weight", (int64_t)V * d));
+  ok = ok && (pos = up.f32("embed_positions.weight", (int64_t)(cfg.max_positions + cfg.pad_idx + 1) * d));
+  ok = ok && up.ln(ln_before, "emb_layer_norm_before", d);
+  ok = ok && up.ln(ln_after, "emb_layer_norm_after", d);
+  ok = ok && up.dense(head_dense, {"lm_head.dense"}, {1.0f}, d, d);
+  ok = ok && up.ln(head_ln, "lm_head.layer_norm", d);
+  ok = ok && (head_bias = up.f32("lm_head.bias", V));
+  if (ok && cfg.arch == PG_ARCH_ESM1B) {
+    esm_layers.resize(cfg.n_layers);
+    for (int i = 0; ok && i < cfg.n_layers; ++i) {
+      const std::string p = "layers." + std::to_string(i) + ".";
+      EsmLayer& L = esm_layers[i];
+      ok = ok && up.ln(L.ln1, p + "self_attn_layer_norm", d);
+      ok = ok && up.dense(L.qkv, {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"}, {qs, 1.f, 1.f}, d, d);
+      ok = ok && up.dense(L.out, {p + "self_attn.out_proj"}, {1.f}, d, d);
+      ok = ok && up.ln(L.ln2, p + "final_layer_norm", d);
+      ok = ok && up.dense(L.fc1, {p + "fc1"}, {1.f}, f, d);
+      ok = ok && up.dense(L.fc2, {p + "fc2"}, {1.f}, d, f);
+    }
+  } else if (ok) {
+    ok = ok && (msa_pos = up.f32("msa_position_embedding", (int64_t)cfg.max_msa_rows * d));
+    msa_layers.resize(cfg.n_layers);
+    for (int i = 0; ok && i < cfg.n_layers; ++i) {
+      const std::string p = "layers." + std::to_string(i) + ".";
+      MsaLayer& L = msa_layers[i];
+      const std::string r = p + "row_self_attention.", cpre = p + "column_self_attention.", ff = p + "feed_forward_layer.";
+      ok = ok && up.ln(L.ln_row, r + "layer_norm", d);
+      ok = ok && up.dense(L.row_qkv, {r + "layer.q_proj", r + "layer.k_proj", r + "layer.v_proj"}, {1.f, 1.f, 1.f}, d, d);
+      ok = ok && up.dense(L.row_out, {r + "layer.out_proj"}, {1.f}, d, d);
+      ok = ok && up.ln(L.ln_col, cpre + "layer_norm", d);
+      ok = ok && up.dense(L.col_qkv, {cpre + "layer.q_proj", cpre + "layer.k_proj", cpre + "layer.v_proj"}, {qs, 1.f, 1.f}, d, d);
+      ok = ok && up.dense(L.col_out, {cpre + "layer.out_proj"}, {1.f}, d, d);
+      ok = ok && up.ln(L.ln_ffn, ff + "layer_norm", d);
+      ok = ok && up.dense(L.fc1, {ff + "layer.fc1"}, {1.f}, f, d);
+      ok = ok && up.dense(L.fc2, {ff + "layer.fc2"}, {1.f}, d, f);
+    }
+  }
+  if (!ok) return fail(PG_ERR_WEIGHTS, up.err.empty() ? std::string("weight upload failed") : up.err);
+  PG_HIP(hipStreamSynchronize(stream));
+  return PG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ESM-1b forward: tokens[B][T] -> x[B*T][d] (residual stream before emb_layer_norm_after)
+// ------------------------------------------------------------------------------------------------
+int Engine::esm_trunk(const int32_t* d_tok, int B, int T) {
+  const int d = cfg.d_model, f = cfg.d_ffn;
+  const int64_t M = (int64_t)B * T;
+  const int64_t Mp = round_up64(M, kRowPad);
+  if (Mp > 0x7fffffff / 4) return fail(PG_ERR_INVALID, "too many tokens in one call");
+  int rc;
+  if ((rc = x.ensure((size_t)Mp * d * 4, stream))) return rc;
+  if ((rc = h.ensure((size_t)Mp * d * 2, stream))) return rc;
+  if ((rc = qkv.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;
+  if ((rc = ctx.ensure((size_t)Mp * d * 2, stream))) return rc;
+  if ((rc = ffn.ensure((size_t)Mp * f * 2, stream))) return rc;
+  float* X = x.as<float>();
+  bf16_t* Hh = h.as<bf16_t>();
+  bf16_t* QKV = qkv.as<bf16_t>();
+  bf16_t* CTX = ctx.as<bf16_t>();
+  bf16_t* FFN = ffn.as<bf16_t>();
+  const float eps = cfg.layer_norm_eps;
+  const int Mi = (int)Mp;
+
+  rc = timed(PC_EMBED, [&] {
+    return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
+                           cfg.mask_idx, cfg.token_dropout, 0, eps);
+  });
+  if (rc) return rc;
+  for (int l = 0; l < cfg.n_layers; ++l) {
+    const EsmLayer& L = esm_layers[l];
+    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, Hh, M, d, eps); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return launch_attention_bf16(stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, Hh, M, d, eps); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID); }))) return rc;
+  }
+  return PG_OK;
+}
+
+// LM head evaluated ONLY at the selected rows: emb_layer_norm_after -> dense -> GELU ->
+// LayerNorm -> tied decoder + bias.  d_idx == nullptr: every one of the n_sel rows of x in order.
+int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits) {
+  const int d = cfg.d_model, V = cfg.vocab;
+  const int64_t Np = round_up64(n_sel, kRowPad);
+  int rc;
+  if ((rc = sel_h.ensure((size_t)Np * d * 2, stream))) return rc;
+  if ((rc = sel_g.ensure((size_t)Np * d * 4, stream))) return rc;
+  const float eps = cfg.layer_norm_eps;
+  return timed(PC_HEAD, [&] {
+    int r = launch_gather_ln_bf16(stream, x.as<float>(), d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
+                                  sel_h.as<bf16_t>(), n_sel, d, eps);
+    if (r) return r;
+    r = launch_gemm_bf16(stream, sel_h.as<bf16_t>(), head_dense.w, head_dense.b, sel_g.as<float>(), (int)Np, d, d, d, d, d,
+                         EPI_F32_GELU);
+    if (r) return r;
+    return launch_lm_tail(stream, sel_g.as<float>(), head_ln.g, head_ln.b, embed, head_bias, d_logits, n_sel, d, V, eps);
+  });
+}
+
+int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_, int n_iters, int P,
+                             const pg_sample_params* sp, float* d_samp_logits_, int32_t* d_samp_tok_) {
+  if (cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
+  if (B < 0 || T < 1 || P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "gibbs: negative size");
+  if (T > cfg.max_positions + 2) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
+  if (B == 0 || n_iters == 0) return PG_OK;
+  const int V = cfg.vocab;
+  const int64_t n_sel_rows = B;              // one selected token row per chain
+  const int64_t n_draws = (int64_t)B * P;
+  int rc;
+  if (!d_samp_logits_ && (rc = logits.ensure((size_t)(n_draws > 0 ? n_draws : 1) * V * 4, stream))) return rc;
+  for (int it = 0; it < n_iters; ++it) {
+    const int32_t* idx_it = d_idx_ + (size_t)it * n_draws;
+    if (sp->mask && P > 0)
+      if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, T, idx_it, nullptr, n_sel_rows, P, sp->mask_idx); }))) return rc;
+    if ((rc = esm_trunk(d_tok, B, T))) return rc;
+    if (P == 0) continue;
+    float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)it * n_draws * V : logits.as<float>();
+    if ((rc = head(idx_it, nullptr, P, T, n_draws, lg))) return rc;
+    int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)it * n_draws : nullptr;
+    if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, T, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, it, st); }))) return rc;
+  }
+  return PG_OK;
+}
+
+}  // namespace pg

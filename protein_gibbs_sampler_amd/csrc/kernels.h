@@ -1,0 +1,40 @@
+// Launchers of the gfx950 kernels (one translation unit per kernel family).
+#pragma once
+#include "pg_common.h"
+
+#include "../../include/pgibbs.h"
+
+namespace pg {
+
+enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_GELU = 4 };
+
+// out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M, N multiples of 128, K of 64 (buffers are row-padded).
+int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
+                     int ldx, int ldw, int ldo, int epi);
+
+// fused attention, one (sequence, head) per workgroup; qkv rows are [q | k | v] with head h at h*64
+int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
+                          int k_off, int v_off);
+
+int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
+                    const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,
+                    int mask_idx, int token_dropout, int rows_per_msa, float eps);
+int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
+                          int d, float eps);
+int launch_layernorm_f32(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t M, int d,
+                         float eps);
+int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, const int32_t* row_map, int P, int width,
+                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps);
+int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const float* beta, const float* embed,
+                   const float* out_bias, float* logits, int64_t n, int d, int V, float eps);
+int launch_f32_to_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t n, float scale);
+int launch_bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n);
+int launch_scale_f32(hipStream_t s, float* p, int64_t n, float scale);
+
+int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
+                        int64_t n_sel, int P, int mask_idx);
+int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const float* logits, int V, int compact,
+                            const int32_t* idx, const int32_t* row_map, int64_t n_sel, int P, const pg_sample_params* p,
+                            int iteration, int32_t* sampled_tokens);
+
+}  // namespace pg

@@ -1,0 +1,193 @@
+// The two integer/index ends of a Gibbs iteration, as data-parallel kernels:
+//
+//   mask_scatter_kernel      == mask_target_indexes           /root/reference/src/pgen/esm_sampler.py:259-262,
+//                               (+ _single)                    esm_msa_sampler.py:255-264
+//   sample_writeback_kernel  == generate_step + write-back    esm_sampler.py:8-45, 225-234;
+//                                                              esm_msa_sampler.py:138-145, 238-248
+//
+// In the reference both are Python loops issuing B*P scalar tensor writes (6400 per iteration at
+// config 2).  All P draws of an iteration read the same logits (no re-forward between positions), so
+// they are independent: one thread per (row, slot).  A row of 33 logits is 132 B; the whole job is a
+// few hundred KB -> latency-bound, one launch each.
+//
+// The draw is "pg_draw v1" (oracle/draw.py): every float op below is a separately rounded IEEE
+// binary32 op -- this file is compiled with -ffp-contract=off -- so the kernel and the CPU oracle
+// agree bit-for-bit given the same logits.
+#include "../../include/pgibbs.h"
+#include "kernels.h"
+
+namespace pg {
+
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t& o0) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o0 = c0;
+}
+
+// exp(x), x <= 0, reproducible (oracle/draw.py::pg_exp)
+__device__ __forceinline__ float pg_exp(float x) {
+  const float z = x * 1.44269502162933349609375f;  // float32(log2 e)
+  if (z < -126.0f) return 0.0f;
+  const float n = floorf(z);
+  const float f = z - n;
+  float p = 0x1.b4d1dep-13f;
+  p = p * f; p = p + 0x1.4ca4cep-10f;
+  p = p * f; p = p + 0x1.3c4a8ap-7f;
+  p = p * f; p = p + 0x1.c69f6ap-5f;
+  p = p * f; p = p + 0x1.ebfc40p-3f;
+  p = p * f; p = p + 0x1.62e430p-1f;
+  p = p * f; p = p + 1.0f;
+  const int bits = __float_as_int(p) + ((int)n << 23);
+  return __int_as_float(bits);
+}
+
+struct SampleArgs {
+  int32_t top_k;
+  int32_t sample;       // 1: draw from all valid tokens regardless of top_k
+  float temperature;
+  int32_t use_temp;
+  int32_t n_valid;
+  int32_t valid_idx[32];
+  uint32_t seed_lo, seed_hi, stream, row_id_base, iter;
+};
+
+// logits addressing: compact [n_sel*P][V] (engine path: LM head evaluated only at the sampled rows),
+// or full [n_rows][width][V] (plug-in models).
+__global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restrict__ tokens, int width,
+                                                              const float* __restrict__ logits, int V, int compact,
+                                                              const int32_t* __restrict__ idx,
+                                                              const int32_t* __restrict__ row_map, int64_t n_sel, int P,
+                                                              SampleArgs a, int32_t* __restrict__ sampled_tokens) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_sel * P) return;
+  const int64_t s = i / P;
+  const int slot = (int)(i - s * P);
+  const int raw = idx[i];
+  if (raw < 0) {
+    if (sampled_tokens) sampled_tokens[i] = -1;
+    return;
+  }
+  const int pos = raw & 0x3fffffff;
+  const int64_t trow = row_map ? (int64_t)row_map[s] : s;
+  const float* row = compact ? logits + (size_t)i * V : logits + ((size_t)trow * width + pos) * V;
+
+  const int nv = a.n_valid;
+  int k = a.top_k;
+  if (a.sample || k <= 0 || k > nv) k = nv;
+  float sv[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float v = 0.f;
+    if (j < nv) {
+      v = row[a.valid_idx[j]];
+      if (a.use_temp) v = v / a.temperature;
+    }
+    sv[j] = v;
+  }
+  // stable descending rank of every valid entry
+  float ev[32];   // values in rank order
+  int ei[32];     // valid-list position in rank order
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    if (j < nv) {
+      int rank = 0;
+#pragma unroll
+      for (int m = 0; m < 32; ++m)
+        if (m < nv) rank += (sv[m] > sv[j]) || (sv[m] == sv[j] && m < j);
+      // scatter by rank (rank is a permutation of 0..nv-1)
+#pragma unroll
+      for (int m = 0; m < 32; ++m)
+        if (m == rank) { ev[m] = sv[j]; ei[m] = j; }
+    }
+  }
+  const float top = ev[0];
+  float cum[32];
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    if (r < k) {
+      const float e = pg_exp(ev[r] - top);
+      acc = (r == 0) ? e : acc + e;
+      cum[r] = acc;
+    }
+  }
+  uint32_t w0;
+  philox4x32_10(a.row_id_base + (uint32_t)s, a.iter, (uint32_t)slot, a.stream, a.seed_lo, a.seed_hi, w0);
+  const float u = (float)(w0 >> 8) * 0x1.0p-24f;
+  const float t = u * acc;
+  int jsel = k - 1;
+#pragma unroll
+  for (int r = 31; r >= 0; --r)
+    if (r < k && cum[r] > t) jsel = r;
+  int pick = 0;
+#pragma unroll
+  for (int r = 0; r < 32; ++r)
+    if (r == jsel) pick = ei[r];
+  const int tok = a.valid_idx[pick];
+  if (sampled_tokens) sampled_tokens[i] = tok;
+  if (!(raw & 0x40000000)) tokens[trow * width + pos] = tok;
+}
+
+__global__ __launch_bounds__(256) void mask_scatter_kernel(int32_t* __restrict__ tokens, int width,
+                                                          const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ row_map, int64_t n_sel, int P,
+                                                          int mask_idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_sel * P) return;
+  const int raw = idx[i];
+  if (raw < 0) return;
+  const int64_t s = i / P;
+  const int64_t trow = row_map ? (int64_t)row_map[s] : s;
+  tokens[trow * width + (raw & 0x3fffffff)] = mask_idx;
+}
+
+int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
+                        int64_t n_sel, int P, int mask_idx) {
+  const int64_t n = n_sel * P;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, width, idx, row_map,
+                     n_sel, P, mask_idx);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const float* logits, int V, int compact,
+                            const int32_t* idx, const int32_t* row_map, int64_t n_sel, int P, const pg_sample_params* p,
+                            int iteration, int32_t* sampled_tokens) {
+  if (p->n_valid < 1 || p->n_valid > 32) return fail(1, "sample: n_valid must be in 1..32");
+  for (int j = 0; j < p->n_valid; ++j)
+    if (p->valid_idx[j] < 0 || p->valid_idx[j] >= V) return fail(1, "sample: valid_idx out of range");
+  const int64_t n = n_sel * P;
+  if (n == 0) return 0;
+  SampleArgs a;
+  a.top_k = p->top_k;
+  a.sample = iteration < p->burnin ? 1 : 0;   // sample=(ii < burnin), esm_sampler.py:231
+  a.use_temp = (p->temperature == p->temperature) ? 1 : 0;  // NaN == None
+  a.temperature = a.use_temp ? p->temperature : 1.0f;
+  a.n_valid = p->n_valid;
+  for (int j = 0; j < 32; ++j) a.valid_idx[j] = j < p->n_valid ? p->valid_idx[j] : 0;
+  a.seed_lo = (uint32_t)(p->rng_seed & 0xffffffffu);
+  a.seed_hi = (uint32_t)(p->rng_seed >> 32);
+  a.stream = p->rng_stream;
+  a.row_id_base = p->row_id_base;
+  a.iter = (uint32_t)(p->iter_base + iteration);
+  hipLaunchKernelGGL(sample_writeback_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, width, logits, V,
+                     compact, idx, row_map, n_sel, P, a, sampled_tokens);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace pg

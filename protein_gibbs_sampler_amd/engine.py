@@ -1,0 +1,156 @@
+"""`NativeMaskedLM`: the object that sits where the reference expects `model.model`.
+
+In the reference `model.model` is a fair-esm nn.Module (`/root/reference/src/pgen/models.py:61,86`)
+called as `self.model.model(batch)["logits"]` (esm_sampler.py:223, esm_msa_sampler.py:136,236) after
+`.eval()` (esm_sampler.py:62) and `.to(device)` (:80).  Here it is a handle to the HIP engine
+(C ABI `pg_engine_*`); besides the reference's call protocol it exposes `gibbs_run*`, which runs the
+whole iteration loop on the device in one native call.
+"""
+import ctypes
+import re
+
+import numpy as np
+
+from . import _lib
+
+
+class NativeMaskedLM:
+    def __init__(self, cfg, state_dict, precision="bf16"):
+        self.cfg = dict(cfg)
+        self.state_dict = state_dict       # name -> float32 ndarray (host master copy)
+        self.precision = {"bf16": _lib.PG_PREC_BF16, "fp32": _lib.PG_PREC_FP32}[precision]
+        self._h = None
+        self.device = "cpu"
+
+    # ---- nn.Module-ish protocol used by the samplers -------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = str(device)
+        if device == self.device and (self._h is not None or device == "cpu"):
+            return self
+        self._destroy()
+        self.device = device
+        if device == "cpu":
+            return self       # host-only object: tokenisation/index helpers work, forward() raises
+        m = re.match(r"^cuda:([0-9]+)$", device)
+        if not m:
+            raise Exception("Invalid device: " + device)
+        L = _lib.lib()
+        c = _lib.ModelConfig(**{k: self.cfg[k] for k, _ in _lib.ModelConfig._fields_})
+        names = sorted(self.state_dict)
+        arr = (_lib.Tensor * len(names))()
+        keep = []
+        for i, n in enumerate(names):
+            a = np.ascontiguousarray(self.state_dict[n], dtype=np.float32)
+            keep.append(a)
+            arr[i].name = n.encode()
+            arr[i].data = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+            arr[i].numel = a.size
+        h = ctypes.c_void_p()
+        _lib.check(L.pg_engine_create(ctypes.byref(c), arr, len(names), int(m.group(1)), self.precision, ctypes.byref(h)))
+        self._h = h
+        return self
+
+    def cuda(self, device=0):
+        return self.to("cuda:%d" % device if isinstance(device, int) else device)
+
+    def _destroy(self):
+        h, self._h = self._h, None
+        if h:
+            _lib.lib().pg_engine_destroy(h)
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError("the HIP engine is not resident on a GPU (device=%r): call .to('cuda:N') on an MI355X; "
+                               "there is no CPU implementation of the forward pass" % self.device)
+        return self._h
+
+    @property
+    def is_msa(self):
+        return self.cfg["arch"] == _lib.PG_ARCH_MSA1B
+
+    # ---- forward: tokens -> {"logits": ...} ------------------------------------------------
+    def __call__(self, tokens):
+        import torch
+        t = tokens.detach().cpu().numpy() if hasattr(tokens, "detach") else np.asarray(tokens)
+        logits = self.forward_logits(t)
+        out = torch.from_numpy(logits)
+        if hasattr(tokens, "device") and tokens.device.type == "cuda":
+            out = out.to(tokens.device)
+        return {"logits": out}
+
+    def forward_logits(self, tokens):
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        V = self.cfg["vocab"]
+        L = _lib.lib()
+        if self.is_msa:
+            B, R, C = tok.shape
+            out = np.empty((B, R, C, V), dtype=np.float32)
+            _lib.check(L.pg_msa_forward_logits(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(out)))
+        else:
+            B, T = tok.shape
+            out = np.empty((B, T, V), dtype=np.float32)
+            _lib.check(L.pg_esm_forward_logits(self.handle, _lib.ptr(tok), B, T, _lib.ptr(out)))
+        return out
+
+    # ---- whole Gibbs loops -----------------------------------------------------------------
+    def gibbs_run(self, tokens, target_idx, params, want_logits=False, want_tokens=False):
+        """tokens int32 [B,T] or [B,R,C] (modified in place); target_idx int32 [iters, B, P] / [iters, B, R, P]."""
+        tok = tokens
+        assert tok.dtype == np.int32 and tok.flags.c_contiguous
+        idx = np.ascontiguousarray(target_idx, dtype=np.int32)
+        n_iters, P = idx.shape[0], idx.shape[-1]
+        V = self.cfg["vocab"]
+        lg = np.empty(idx.shape + (V,), dtype=np.float32) if want_logits else None
+        st = np.empty(idx.shape, dtype=np.int32) if want_tokens else None
+        L = _lib.lib()
+        if self.is_msa:
+            B, R, C = tok.shape
+            _lib.check(L.pg_msa_gibbs_run(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(idx), n_iters, P, ctypes.byref(params),
+                                          _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None))
+        else:
+            B, T = tok.shape
+            _lib.check(L.pg_esm_gibbs_run(self.handle, _lib.ptr(tok), B, T, _lib.ptr(idx), n_iters, P, ctypes.byref(params),
+                                          _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None))
+        return lg, st
+
+    def gibbs_single_run(self, tokens, mask_row, target_row, step_idx, step_sample, params, want_logits=False,
+                         want_tokens=False):
+        tok = tokens
+        assert tok.dtype == np.int32 and tok.flags.c_contiguous and tok.ndim == 3 and tok.shape[0] == 1
+        _, R, C = tok.shape
+        idx = np.ascontiguousarray(step_idx, dtype=np.int32)
+        flags = np.ascontiguousarray(step_sample, dtype=np.int32)
+        n_steps, P = idx.shape
+        V = self.cfg["vocab"]
+        lg = np.empty((n_steps, P, V), dtype=np.float32) if want_logits else None
+        st = np.empty((n_steps, P), dtype=np.int32) if want_tokens else None
+        _lib.check(_lib.lib().pg_msa_gibbs_single_run(self.handle, _lib.ptr(tok), R, C, mask_row, target_row, _lib.ptr(idx),
+                                                     _lib.ptr(flags), n_steps, P, ctypes.byref(params),
+                                                     _lib.ptr(lg) if want_logits else None,
+                                                     _lib.ptr(st) if want_tokens else None))
+        return lg, st
+
+    # ---- measurement -------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        _lib.check(_lib.lib().pg_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self):
+        _lib.check(_lib.lib().pg_prof_reset(self.handle))
+
+    def prof_get(self, kernel_class):
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        _lib.check(_lib.lib().pg_prof_get(self.handle, kernel_class.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def synchronize(self):
+        _lib.check(_lib.lib().pg_engine_synchronize(self.handle))

@@ -1,0 +1,242 @@
+"""Drop-in for `pgen.esm_sampler` (/root/reference/src/pgen/esm_sampler.py): same class, method names,
+arguments, defaults, exceptions and messages; the per-iteration work runs on an MI355X.
+
+What is kept verbatim in behaviour (citations = reference lines):
+  * device grammar "cpu" | "gpu" | "cuda:N" and its three error messages            :66-78
+  * seed cleaning / "<mask>" padding / list seeds drawn with random.choices           :95-126
+  * num_positions / leader_length derivation and clamps, `indexes` rebinding (Q1)     :186-207
+  * consumption order of the interpreter's RNG (choices per batch, sample per chain)  :112, :242-246
+  * last-batch truncation, untokenize with "<mask>" left as text (Q6)                  :84-93, :236-239
+What changes: the Python loops of :209-234 become one native call per batch
+(`NativeMaskedLM.gibbs_run`), or -- for plug-in models that are not the HIP engine -- a device loop
+whose mask scatter and draw are HIP kernels (`_gibbs.run_plugin_loop`).  The token draw uses the
+engine's counter-based generator (pg_draw v1) keyed from torch's global RNG, since torch's serial
+CPU multinomial stream cannot be reproduced by a data-parallel kernel (DESIGN.md "RNG contract").
+"""
+import ctypes
+import math
+import random
+import re
+
+import numpy as np
+import torch
+from tqdm import trange
+
+from . import _gibbs, _lib
+from .engine import NativeMaskedLM
+
+ESM_ALLOWED_AMINO_ACIDS = "ACDEFGHIKLMNPQRSTVWY"
+
+_step_counter = [0]
+
+
+def _device_of(t):
+    return t.device if isinstance(t, torch.Tensor) else torch.device("cpu")
+
+
+def generate_step(out, gen_idx, temperature=None, top_k=0, sample=False, valid_idx=None, rng_seed=None, counter=None):
+    """Generate a token id from out[gen_idx] (reference :8-45) on the GPU.
+
+    out: logits [seq_len, vocab] (tensor or array); returns a 0-d int64 tensor like the reference.
+    The draw is the HIP kernel behind pg_sample_writeback_device with P = 1.  `rng_seed`/`counter`
+    pin the draw; by default a fresh counter value is used per call and the key comes from torch's
+    global generator, so repeated calls are independent draws as in the reference.
+    """
+    if not torch.cuda.is_available():
+        raise RuntimeError("generate_step needs an MI355X: the draw is a HIP kernel, there is no CPU implementation")
+    dev = out.device if isinstance(out, torch.Tensor) and out.device.type == "cuda" else torch.device("cuda:0")
+    logits = torch.as_tensor(out, dtype=torch.float32).to(dev).contiguous()
+    if logits.dim() != 2:
+        raise ValueError("out must be [seq_len, vocab]")
+    width, V = logits.shape
+    if valid_idx is None:
+        valid_idx = list(range(V))
+    if len(valid_idx) > 32:
+        raise ValueError("at most 32 valid tokens are supported")
+    if rng_seed is None:
+        rng_seed = int(torch.randint(0, 2**62, (1,)).item())
+    if counter is None:
+        counter = _step_counter[0]
+        _step_counter[0] += 1
+    params = _lib.make_sample_params(False, 0, top_k, float("inf") if sample else 0, temperature, list(valid_idx), rng_seed,
+                                     rng_stream=counter >> 32, row_id_base=counter & 0xFFFFFFFF)
+    tok = torch.zeros((1, width), dtype=torch.int32, device=dev)
+    idx = torch.tensor([[int(gen_idx) % width]], dtype=torch.int32, device=dev)
+    picked = torch.empty((1, 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.lib().pg_sample_writeback_device(stream, ctypes.c_void_p(tok.data_ptr()), 1, width,
+                                                         ctypes.c_void_p(logits.data_ptr()), V, ctypes.c_void_p(idx.data_ptr()),
+                                                         None, 1, 1, ctypes.byref(params), 0,
+                                                         ctypes.c_void_p(picked.data_ptr())))
+    return torch.tensor(int(picked.item()))
+
+
+class ESM_sampler():
+    """adapted from bert-gen bert-babble.ipynb (via pgen.esm_sampler.ESM_sampler)"""
+
+    def __init__(self, model, device="cpu"):
+        """model: an object with attributes model, alphabet and batch_converter (reference :54-58)."""
+        self.model = model
+        self.model.model = self.model.model.eval()
+        self.cuda = False
+        self.device = device
+        if self.device == "gpu":
+            self.device = "cuda:0"
+        if re.match("^cuda:[0-9]+$", self.device):
+            cuda_device_num = int(self.device.split(":")[1])
+            if torch.cuda.is_available():
+                self.cuda = True
+            else:
+                raise Exception("gpu requested, but No Cuda devices found")
+            if cuda_device_num >= torch.cuda.device_count():
+                raise Exception("Invalid cuda device number: " + self.device)
+        elif self.device != "cpu":
+            raise Exception("Invalid device: " + self.device)
+        self.model.model.to(self.device)
+        self.valid_aa_idx = sorted([self.model.alphabet.get_idx(tok) for tok in ESM_ALLOWED_AMINO_ACIDS])
+        # key of the token-draw generator; None -> drawn from torch's global RNG once per generate()
+        self.draw_seed = None
+        self.rng_stream = 0
+        # filled by generate(..., ) when self.record is True: per-batch dicts with tables / sampled logits / tokens
+        self.record = False
+        self.last_run = []
+
+    # ---- helpers with the reference's names ----------------------------------------------------
+    def untokenize_batch(self, batch, bos, eos):
+        start_offset = 1 if bos else 0
+        end_offset = -1 if eos else 0
+        if hasattr(batch, "tolist"):
+            batch = batch.tolist()
+        return ["".join([self.model.alphabet.get_tok(seq[i]) for i in range(0 + start_offset, len(seq) + end_offset)])
+                for seq in batch]
+
+    @staticmethod
+    def clean_seed_seq(seed_to_clean):
+        cleaned_seq = seed_to_clean.upper()
+        input_chars = {s for s in cleaned_seq}
+        valid_chars = {s for s in ESM_ALLOWED_AMINO_ACIDS}
+        if not input_chars.issubset(valid_chars):
+            raise (Exception("Invalid input character: " + ",".join(input_chars - valid_chars)))
+        return cleaned_seq
+
+    def get_init_seq(self, seed_seq, max_len, batch_size=1):
+        """Get initial sequence by padding seed_seq with masks (reference :104-126)."""
+        if isinstance(seed_seq, list):
+            batch = random.choices(seed_seq, k=batch_size)
+            for i, seed in enumerate(batch):
+                remaining_len = max_len - len(seed)
+                batch[i] = (str(i), self.clean_seed_seq(seed) + "<mask>" * remaining_len)
+        elif isinstance(seed_seq, str):
+            remaining_len = max_len - len(seed_seq)
+            seed_seq = self.clean_seed_seq(seed_seq)
+            batch = [(str(i), seed_seq + "<mask>" * remaining_len) for i in range(batch_size)]
+        else:
+            raise (Exception("seed sequence should either be a string or list"))
+        labels, strs, tokens = self.model.batch_converter(batch)
+        return tokens
+
+    def get_random_target_index(self, batch_size, indexes, num_positions):
+        """== [random.sample(indexes, num_positions) for b in range(batch_size)] (reference :242-246),
+        produced by the native CPython-exact generator on the interpreter's global RNG state."""
+        from . import pyrandom
+        return pyrandom.global_sample_table(list(indexes), num_positions, batch_size).tolist()
+
+    def get_target_index_in_order(self, batch_size, indexes, next_i, num_positions):
+        last_i, target = _gibbs.in_order_window(indexes, next_i, num_positions)
+        return last_i, [target] * batch_size
+
+    def mask_target_indexes(self, batch, target_indexes):
+        """Reference :259-262.  Nested lists (as in the reference's unit test) are masked on the host; a
+        device token tensor goes through the HIP scatter kernel."""
+        mask_idx = self.model.alphabet.mask_idx
+        if isinstance(batch, torch.Tensor) and batch.device.type == "cuda":
+            P = max((len(t) for t in target_indexes), default=0)
+            table = np.full((len(target_indexes), P), -1, dtype=np.int32)
+            for b, t in enumerate(target_indexes):
+                table[b, :len(t)] = t
+            tok = batch.to(torch.int32).contiguous()
+            d_table = torch.from_numpy(table).to(batch.device)
+            with torch.cuda.device(batch.device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(batch.device).cuda_stream)
+                _lib.check(_lib.lib().pg_mask_scatter_device(stream, ctypes.c_void_p(tok.data_ptr()), tok.shape[0], tok.shape[1],
+                                                             ctypes.c_void_p(d_table.data_ptr()), None, len(target_indexes), P,
+                                                             mask_idx))
+            batch.copy_(tok.to(batch.dtype))
+            return
+        for batch_index in range(len(target_indexes)):
+            for kk in target_indexes[batch_index]:
+                batch[batch_index][kk] = mask_idx
+
+    def calculate_indexes(self, indexes, leader_length, max_len, rollover_from_start):
+        if indexes is None:
+            indexes = range(1, max_len + 1)  # skip position 0: <cls>
+            if not rollover_from_start:
+                indexes = indexes[leader_length:]
+                last_i = leader_length - 1
+            else:
+                last_i = -1
+        else:
+            last_i = -1
+        return indexes, last_i
+
+    # ---- the sampler -----------------------------------------------------------------------------
+    def generate(self, n_samples, seed_seq, batch_size=1, in_order=False, max_len=None, leader_length=0,
+                 leader_length_percent=None, top_k=0, temperature=None, num_iters=10, burnin=float('inf'), mask=True,
+                 num_positions=0, num_positions_percent=None, indexes=None, rollover_from_start=False,
+                 show_progress_bar=True):
+        """generate sequences -- arguments exactly as pgen.esm_sampler.ESM_sampler.generate (reference :128-170)."""
+        if isinstance(seed_seq, str):
+            sequence_length = len(seed_seq)
+        elif isinstance(seed_seq, list):
+            sequence_length = max(len(seed) for seed in seed_seq)
+        else:
+            raise ValueError("Unknown seed sequence format, expecting str or list")
+
+        sequences = []
+        n_batches = math.ceil(n_samples / batch_size)
+        if max_len is None:
+            max_len = sequence_length
+        if num_positions_percent is not None:
+            num_positions = int(max_len * (num_positions_percent / 100))
+        if num_positions < 0:
+            num_positions = 0
+        if leader_length_percent is not None:
+            leader_length = int(max_len * (leader_length_percent / 100))
+        if leader_length < 0:
+            leader_length = 0
+
+        if not self.cuda:
+            raise RuntimeError("ESM_sampler.generate needs device 'gpu'/'cuda:N' on an MI355X: this package implements the "
+                               "Gibbs hot path as HIP kernels only and has no CPU implementation")
+        draw_seed = self.draw_seed if self.draw_seed is not None else int(torch.randint(0, 2**62, (1,)).item())
+        native = isinstance(self.model.model, NativeMaskedLM)
+        self.last_run = []
+
+        for batch_n in trange(n_batches, disable=(not show_progress_bar)):
+            batch = self.get_init_seq(seed_seq, max_len, batch_size)
+
+            indexes, last_i = self.calculate_indexes(indexes, leader_length, max_len, rollover_from_start)
+            if num_positions > len(indexes):
+                num_positions = len(indexes)
+
+            table, last_i = _gibbs.build_target_table(num_iters, (batch_size,), indexes, num_positions, in_order, last_i)
+            params = _lib.make_sample_params(mask, self.model.alphabet.mask_idx, top_k, burnin, temperature, self.valid_aa_idx,
+                                             draw_seed, rng_stream=self.rng_stream, row_id_base=batch_n * batch_size)
+            if native:
+                tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)
+                lg, st = self.model.model.gibbs_run(tok, table, params, want_logits=self.record, want_tokens=self.record)
+                batch = torch.from_numpy(tok.astype(np.int64))
+                if self.record:
+                    self.last_run.append(dict(table=table, sampled_logits=lg, sampled_tokens=st, tokens=tok.copy()))
+            else:
+                batch = _gibbs.run_plugin_loop(self.model.model, batch, table, params, self.device)
+                if self.record:
+                    self.last_run.append(dict(table=table, tokens=batch.numpy().copy()))
+
+            strs = self.untokenize_batch(batch, self.model.alphabet.prepend_bos, self.model.alphabet.append_eos)
+            if batch_n == (n_batches - 1):
+                sequences += strs[0:n_samples - len(sequences)]
+            else:
+                sequences += strs
+        return sequences

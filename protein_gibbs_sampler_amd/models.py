@@ -1,0 +1,67 @@
+"""Model wrappers with the three attributes the samplers expect: `.model`, `.alphabet`,
+`.batch_converter` -- the plug-in contract of /root/reference/src/pgen/models.py:59-88.
+
+`.model` is a NativeMaskedLM (HIP engine handle) instead of a fair-esm nn.Module.  Weights: a real
+fair-esm checkpoint when one is given or found in torch's hub cache, otherwise seeded synthetic
+weights of the same architecture (a warning is printed: samples are then not biologically meaningful).
+"""
+import warnings
+
+from . import weights as _w
+from .alphabet import Alphabet
+from .engine import NativeMaskedLM
+
+
+def _resolve_weights(cfg, state_dict, checkpoint, filename, seed):
+    if state_dict is not None:
+        return state_dict
+    path = checkpoint or _w.find_cached_checkpoint(filename)
+    if path:
+        return _w.load_fair_esm_checkpoint(path, cfg)
+    warnings.warn("no %s checkpoint available offline: using seeded synthetic weights (seed=%d)" % (filename, seed))
+    return _w.synthetic_state_dict(cfg, seed=seed)
+
+
+class _Wrapper:
+    def __init__(self, cfg, alphabet, msa, state_dict, checkpoint, filename, seed, precision):
+        self.cfg = cfg
+        self.alphabet = alphabet
+        self.batch_converter = alphabet.get_batch_converter(msa=msa)
+        self.model = NativeMaskedLM(cfg, _resolve_weights(cfg, state_dict, checkpoint, filename, seed), precision)
+
+
+class ESM1b(_Wrapper):
+    """esm1b_t33_650M_UR50S (models.py:59-62)."""
+
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None):
+        super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
+                         "esm1b_t33_650M_UR50S.pt", seed, precision)
+
+
+class ESM1v(_Wrapper):
+    """esm1v_t33_650M_UR90S (models.py:64-67): same architecture as ESM-1b, different weights."""
+
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None):
+        super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
+                         "esm1v_t33_650M_UR90S_1.pt", seed, precision)
+
+
+class ESM_MSA1(_Wrapper):
+    """esm_msa1b_t12_100M_UR50S (models.py:84-88) with the reference's patched MSA batch converter."""
+
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None):
+        super().__init__(config or dict(_w.MSA1B_CONFIG), Alphabet(True, False), True, state_dict, checkpoint,
+                         "esm_msa1b_t12_100M_UR50S.pt", seed, precision)
+
+
+def _esm1_unsupported(name):
+    def ctor(*a, **k):
+        raise NotImplementedError(
+            name + " is an ESM-1 (sinusoidal positions, no token dropout) model; this engine implements the "
+            "ESM-1b and ESM-MSA-1b architectures that the Gibbs hot path is benchmarked on")
+    return ctor
+
+
+ESM6 = _esm1_unsupported("esm1_t6_43M_UR50S")
+ESM12 = _esm1_unsupported("esm1_t12_85M_UR50S")
+ESM34 = _esm1_unsupported("esm1_t34_670M_UR50S")

@@ -1,0 +1,70 @@
+"""Kernel-level parity on the MI355X, each kernel through its C-ABI debug entry point against numpy:
+bf16 MFMA GEMM (+ fused epilogues), LayerNorm, fused attention.  Inputs are asymmetric/random so a
+transposed operand or output cannot pass."""
+import numpy as np
+import pytest
+
+from protein_gibbs_sampler_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(a):
+    """round-to-nearest-even to bfloat16, returned as float32 (numpy restatement for the comparison)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x * 0.7071067811865476))
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 128, 0), (70, 128, 64, 0), (256, 384, 256, 1), (513, 1280, 1280, 0),
+                                       (1000, 512, 5120, 1)])
+def test_gemm_bf16(M, N, K, epi):
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
+    x[:, 0] += np.arange(M, dtype=np.float32) * 0.01        # break any row/col symmetry
+    b = rng.standard_normal(N, dtype=np.float32)
+    out = np.empty((M, N), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_BF16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
+    ref = _bf16(x).astype(np.float64) @ _bf16(w).astype(np.float64).T + b
+    if epi:
+        ref = _gelu(ref)
+    err = np.abs(out - ref).max()
+    assert err < 2e-3 * max(1.0, np.abs(ref).max()), err      # fp32 accumulation-order noise only
+
+
+@pytest.mark.parametrize("M,d", [(5, 128), (1000, 1280), (33, 768), (7, 256)])
+def test_layernorm(M, d):
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((M, d), dtype=np.float32) * 3 + 1).astype(np.float32)
+    g = rng.standard_normal(d, dtype=np.float32)
+    b = rng.standard_normal(d, dtype=np.float32)
+    y = np.empty_like(x)
+    _lib.check(_lib.lib().pg_dbg_layernorm(0, _lib.ptr(x), _lib.ptr(g), _lib.ptr(b), _lib.ptr(y), M, d, 1e-5))
+    x64 = x.astype(np.float64)
+    ref = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * g + b
+    assert np.abs(y - ref).max() < 2e-5 * max(1, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 27, 2), (3, 258, 2), (1, 16, 1), (2, 100, 3), (1, 200, 1), (1, 300, 2), (1, 513, 1)])
+def test_attention(B, T, H):
+    rng = np.random.default_rng(T)
+    d = H * 64
+    qkv = rng.standard_normal((B, T, 3 * d), dtype=np.float32)
+    qkv[..., :d] *= 0.35                                       # q is pre-scaled in the engine
+    ctx = np.empty((B, T, d), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_attention(0, _lib.PG_PREC_BF16, _lib.ptr(qkv), _lib.ptr(ctx), B, T, H))
+    r = _bf16(qkv).astype(np.float64)
+    q, k, v = (r[..., i * d:(i + 1) * d].reshape(B, T, H, 64).transpose(0, 2, 1, 3) for i in range(3))
+    a = q @ k.transpose(0, 1, 3, 2)
+    p = np.exp(a - a.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, T, d)
+    # P and the output are rounded to bf16 (8-bit mantissa): abs error ~ 2^-8 * |ctx|
+    assert np.abs(ctx - ref).max() < 2.5e-2, np.abs(ctx - ref).max()
+    assert np.abs(ctx - ref).mean() < 3e-3

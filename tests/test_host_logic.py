@@ -1,0 +1,179 @@
+"""Host logic of the product (runs without a GPU): tokenisation, index helpers, error messages and the
+position tables of ESM_sampler / ESM_MSA_sampler against the fixtures recorded from the reference
+(tests/golden/*.json) and against the reference's own unit tests (cited per test)."""
+import random
+import warnings
+
+import numpy as np
+import pytest
+
+from protein_gibbs_sampler_amd import _gibbs, esm_msa_sampler, esm_sampler, models, weights
+from _standin import load_json
+
+ESM = load_json("sampler_esm.json")
+MSA = load_json("sampler_msa.json")
+MISC = load_json("misc_ref.json")
+
+
+@pytest.fixture(scope="module")
+def esm():
+    cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=1, d_ffn=256, max_positions=64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return esm_sampler.ESM_sampler(models.ESM1b(config=cfg), device="cpu")
+
+
+@pytest.fixture(scope="module")
+def msa():
+    cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=128, n_layers=1, d_ffn=256, max_positions=64, max_msa_rows=16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return esm_msa_sampler.ESM_MSA_sampler(models.ESM_MSA1(config=cfg), device="cpu")
+
+
+# ---- device grammar (reference esm_sampler.py:66-78; test_esm_sampler.py:39-40) -------------------
+def test_sampler_init_gpu_when_not_available(mock_no_gpu):
+    cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=1, d_ffn=256, max_positions=64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = models.ESM1b(config=cfg)
+    with pytest.raises(Exception) as e:
+        esm_sampler.ESM_sampler(m, device="gpu")
+    assert str(e.value) == "gpu requested, but No Cuda devices found"
+    with pytest.raises(Exception) as e:
+        esm_sampler.ESM_sampler(m, device="tpu")
+    assert str(e.value) == "Invalid device: tpu"
+    with pytest.raises(Exception) as e:
+        esm_msa_sampler.ESM_MSA_sampler(m, device="cuda:x")
+    assert str(e.value) == "Invalid device: cuda:x"
+
+
+def test_generate_without_gpu_fails_loudly(esm, msa):
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        esm.generate(1, "ACD", show_progress_bar=False)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        msa.generate(1, ["ACD", "ACD"], show_progress_bar=False)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        msa.generate_single(["ACD", "ACD"])
+
+
+# ---- tokenisation KATs (test_esm_sampler.py:43-88 with the ESM-1b table; test_esm_msa_sampler.py:43-84) ----
+def test_get_init_seq(esm):
+    assert esm.get_init_seq("", 5, 1).tolist() == [[0, 32, 32, 32, 32, 32, 2]]
+    assert esm.get_init_seq("AA", 5, 1).tolist() == [[0, 5, 5, 32, 32, 32, 2]]
+    assert esm.get_init_seq("aa", 5, 1).tolist() == [[0, 5, 5, 32, 32, 32, 2]]
+    assert esm.get_init_seq(["Aa"], 5, 1).tolist() == [[0, 5, 5, 32, 32, 32, 2]]
+    out = esm.get_init_seq(["AA", "A"], 5, 3)
+    assert len(out) == 3
+    for item in out.tolist():
+        assert item in ([0, 5, 5, 32, 32, 32, 2], [0, 5, 32, 32, 32, 32, 2])
+    with pytest.raises(Exception) as e:
+        esm.get_init_seq("X", 5, 1)
+    assert str(e.value) == "Invalid input character: X"
+    with pytest.raises(Exception) as e:
+        esm.get_init_seq(5, 5, 1)
+    assert str(e.value) == "seed sequence should either be a string or list"
+
+
+def test_clean_seed_errors_match_reference(esm):
+    for s, bad in MISC["esm_clean_errors"].items():
+        if bad is None:
+            esm.clean_seed_seq(s)
+        else:
+            with pytest.raises(Exception) as e:
+                esm.clean_seed_seq(s)
+            assert sorted(str(e.value)[len("Invalid input character: "):].split(",")) == bad
+
+
+def test_msa_tokenisation(msa):
+    assert msa.untokenize_batch([[[0, 5, 5, 5, 32, 32], [0, 5, 25, 25, 32, 32]], [[0, 5, 25, 23, 13, 32]]]) == \
+        ["AAA<mask><mask>", "ABB<mask><mask>", "ABCD<mask>"]
+    r = msa.get_init_msa(["AAA", "ACC", "ACDE"], 5, 2)
+    assert tuple(r.shape) == (2, 3, 6)
+    assert r[0].tolist() == [[0, 5, 5, 5, 32, 32], [0, 5, 23, 23, 32, 32], [0, 5, 23, 13, 9, 32]]
+    assert msa.get_init_msa(["aaa", "aCC", "aCDE"], 5, 2)[1].tolist() == r[0].tolist()
+    with pytest.raises(Exception) as e:
+        msa.get_init_msa(["X"], 2)
+    assert str(e.value) == "Invalid input character: X"
+    with pytest.raises(RuntimeError, match="unaligned"):
+        msa.model.batch_converter([("0", "AAA"), ("1", "AA")])
+
+
+def test_valid_tokens(esm, msa):
+    assert esm.valid_aa_idx == list(range(4, 24))
+    assert msa.valid_aa_idx == list(range(4, 24)) + [30]
+    allowed = {esm.model.alphabet.get_tok(i) for i in esm.valid_aa_idx}
+    assert allowed == set(esm_sampler.ESM_ALLOWED_AMINO_ACIDS) and allowed.issubset(esm.model.alphabet.standard_toks)
+    assert {msa.model.alphabet.get_tok(i) for i in msa.valid_aa_idx}.isdisjoint(set("XBUXZO."))
+
+
+# ---- index helpers (test_esm_sampler.py:130-163; test_esm_msa_sampler.py:132-218) -------------------
+def test_index_helpers(esm, msa):
+    assert esm.get_target_index_in_order(batch_size=2, indexes=[0, 1, 2, 3], next_i=1, num_positions=2) == (3, [[2, 3], [2, 3]])
+    t = esm.get_random_target_index(batch_size=2, indexes=[0, 1, 2, 3], num_positions=3)
+    assert len(t) == 2 and len(t[0]) == 3 and set(t[0]) <= {0, 1, 2, 3}
+    batch = [[1, 1, 1, 1], [1, 1, 1, 1], [1, 1, 1, 1]]
+    esm.mask_target_indexes(batch, [[2, 3], [1, 2], [0, 1]])
+    assert batch == [[1, 1, 32, 32], [1, 32, 32, 1], [32, 32, 1, 1]]
+    last_i, t = msa.get_target_index_in_order(batch_size=2, indexes=[0, 1, 2, 3], next_i=1, num_positions=2, num_sequences=3)
+    assert last_i == 3 and t == [[[2, 3]] * 3] * 2
+    t = msa.get_random_target_index(batch_size=2, indexes=[0, 1, 2, 3], num_positions=2, num_sequences=3)
+    assert len(t) == 2 and len(t[0]) == 3 and len(t[0][0]) == 2
+    assert msa.get_target_indexes_all_positions(2, [0, 1, 2, 3], 3) == [[[0, 1, 2, 3]] * 3] * 2
+    b = [[[1, 1, 1, 1] for _ in range(3)] for _ in range(2)]
+    msa.mask_target_indexes(b, [[[2, 3], [1, 2], [0, 1]], [[0, 1], [2, 1], [3, 2]]])
+    assert b == [[[1, 1, 32, 32], [1, 32, 32, 1], [32, 32, 1, 1]], [[32, 32, 1, 1], [1, 32, 32, 1], [1, 1, 32, 32]]]
+    assert msa.calculate_indexes(None, 1, 5, False) == ([2, 3, 4, 5], 0)
+    assert msa.calculate_indexes(None, 1, 5, True) == ([1, 2, 3, 4, 5], -1)
+    assert msa.calculate_indexes([2, 3, 4, 5], 1, 5, False) == ([2, 3, 4, 5], -1)
+    assert list(esm.calculate_indexes(None, 3, 10, False)[0]) == list(range(4, 11))
+
+
+def test_partition_matches_reference():
+    for rec in MISC["partition"]:
+        assert esm_msa_sampler.partition(list(range(1, rec["n"] + 1)), rec["parts"]) == rec["out"]
+    with pytest.raises(ZeroDivisionError):
+        esm_msa_sampler.partition([], 3)
+
+
+# ---- position tables vs the reference run ------------------------------------------------------------
+def _esm_tables(s, c):
+    """Re-run generate()'s host bookkeeping (no GPU) and return the per-batch tables + init tokens."""
+    kw = dict(c["kw"])
+    n_samples, seed_seq = c["n_samples"], c["seed_seq"]
+    B = kw.get("batch_size", 1)
+    max_len = kw.get("max_len") or (len(seed_seq) if isinstance(seed_seq, str) else max(len(x) for x in seed_seq))
+    num_positions = kw.get("num_positions", 0)
+    if kw.get("num_positions_percent") is not None:
+        num_positions = int(max_len * (kw["num_positions_percent"] / 100))
+    num_positions = max(num_positions, 0)
+    leader = kw.get("leader_length", 0)
+    if kw.get("leader_length_percent") is not None:
+        leader = int(max_len * (kw["leader_length_percent"] / 100))
+    leader = max(leader, 0)
+    indexes = kw.get("indexes")
+    tables, inits = [], []
+    for _ in range(-(-n_samples // B)):
+        inits.append(s.get_init_seq(seed_seq, max_len, B))
+        indexes, last_i = s.calculate_indexes(indexes, leader, max_len, kw.get("rollover_from_start", False))
+        num_positions = min(num_positions, len(indexes))
+        t, last_i = _gibbs.build_target_table(kw.get("num_iters", 10), (B,), indexes, num_positions, kw.get("in_order", False), last_i)
+        tables.append(t)
+    return tables, inits
+
+
+@pytest.mark.parametrize("name", sorted(ESM))
+def test_esm_position_tables_bit_exact(esm, name):
+    c = ESM[name]
+    random.seed(c["pyseed"])
+    tables, inits = _esm_tables(esm, c)
+    got = [t[it].tolist() for t in tables for it in range(t.shape[0])]
+    if c["kw"].get("num_positions", 0) > 0 or c["kw"].get("num_positions_percent") is not None:
+        assert got == c["targets"]
+    assert inits[0].tolist() == c["forward_inputs"][0] or c["kw"].get("mask", True)   # before masking
+    assert random.getrandbits(32) == c["py_state_after"][-1]       # identical RNG consumption
+
+
+def test_duplicate_indexes_are_shadowed():
+    t, _ = _gibbs.build_target_table(1, (2,), [3, 5, 3, 7], 0, False, -1)
+    assert t[0, 0].tolist() == [3 | _gibbs.SHADOW_BIT, 5, 3, 7]
