@@ -151,6 +151,9 @@ int pg_esm_gibbs_run_device(pg_engine*, int32_t* d_tokens_inout, int B, int T, c
 int pg_msa_forward_logits(pg_engine*, const int32_t* tokens, int B, int R, int C, float* logits_out);
 int pg_msa_gibbs_run(pg_engine*, int32_t* tokens_inout, int B, int R, int C, const int32_t* target_idx, int n_iters,
                      int P, const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
+int pg_msa_gibbs_run_device(pg_engine*, int32_t* d_tokens_inout, int B, int R, int C, const int32_t* d_target_idx,
+                            int n_iters, int P, const pg_sample_params* params, float* d_sampled_logits,
+                            int32_t* d_sampled_tokens);
 int pg_msa_gibbs_single_run(pg_engine*, int32_t* tokens_inout, int R, int C, int mask_row, int target_row,
                             const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
                             const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
@@ -181,11 +184,18 @@ int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t*
 /* out[M][N] = x[M][K] @ w[N][K]^T + bias (fp32 host buffers; computed in `precision`); epi: 0 none, 1 gelu */
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi);
+/* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events); variant 1 =
+ * lockstep kernel, 2 = ping-pong kernel; epi: 0 bf16 out, 1 bf16+gelu, 2 fp32 residual, 3 fp32, 4 fp32+gelu */
+int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int iters, double* avg_ms);
 /* y = LayerNorm(x[M][d]) * gamma + beta */
 int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                      float eps);
 /* softmax(q k^T) v per (b, h); q already scaled; qkv[B][T][3*H*64] fp32 -> ctx[B][T][H*64] */
 int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, int B, int T, int H);
+
+/* MSA attention blocks: qkv[B][R][C][3*H*64] fp32 -> ctx[B][R][C][H*64]; which = 0 tied row attention (scores * scale),
+ * 1 column attention (q pre-scaled) */
+int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, int B, int R, int C, int H, float scale);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,8 @@ SIGNATURES = [
     ("pg_msa_forward_logits", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("pg_msa_gibbs_run", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(SampleParams),
                                  c_void_p, c_void_p]),
+    ("pg_msa_gibbs_run_device", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, POINTER(SampleParams),
+                                        c_void_p, c_void_p]),
     ("pg_msa_gibbs_single_run", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                         POINTER(SampleParams), c_void_p, c_void_p]),
     ("pg_mask_scatter_device", c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int]),
@@ -88,8 +90,10 @@ SIGNATURES = [
     ("pg_prof_reset", c_int, [c_void_p]),
     ("pg_prof_get", c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64)]),
     ("pg_dbg_gemm", c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    ("pg_dbg_gemm_bench", c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double)]),
     ("pg_dbg_layernorm", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
     ("pg_dbg_attention", c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
+    ("pg_dbg_msa_attention", c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float]),
 ]
 
 

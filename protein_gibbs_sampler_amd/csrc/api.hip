@@ -136,20 +136,96 @@ int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const in
   return PG_OK;
 }
 
-// ---- ESM-MSA-1b (kernels land in a later milestone of this round) ---------------------------------
-int pg_msa_forward_logits(pg_engine* h, const int32_t*, int, int, int, float*) {
-  (void)h;
-  return fail(PG_ERR_UNSUPPORTED, "MSA-1b forward is not implemented in this build");
+// ---- ESM-MSA-1b -----------------------------------------------------------------------------
+int pg_msa_forward_logits(pg_engine* h, const int32_t* tokens, int B, int R, int C, float* logits_out) {
+  if (!h || !tokens || !logits_out) return fail(PG_ERR_INVALID, "pg_msa_forward_logits: null argument");
+  Engine& e = h->e;
+  if (e.cfg.arch != PG_ARCH_MSA1B) return fail(PG_ERR_INVALID, "engine was not built for the MSA-1b architecture");
+  if (B < 0 || R < 1 || C < 1) return fail(PG_ERR_INVALID, "bad shape");
+  if (B == 0) return PG_OK;
+  DeviceGuard g(e.device);
+  const int64_t M = (int64_t)B * R * C;
+  int rc;
+  if ((rc = e.d_tokens.ensure((size_t)M * 4, e.stream))) return rc;
+  if ((rc = e.logits.ensure((size_t)M * e.cfg.vocab * 4, e.stream))) return rc;
+  PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens, (size_t)M * 4, hipMemcpyHostToDevice, e.stream));
+  if ((rc = e.msa_trunk(e.d_tokens.as<int32_t>(), B, R, C))) return rc;
+  if ((rc = e.head(nullptr, nullptr, 1, C, M, e.logits.as<float>()))) return rc;
+  PG_HIP(hipMemcpyAsync(logits_out, e.logits.p, (size_t)M * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
+  PG_HIP(hipStreamSynchronize(e.stream));
+  return PG_OK;
 }
-int pg_msa_gibbs_run(pg_engine* h, int32_t*, int, int, int, const int32_t*, int, int, const pg_sample_params*, float*,
-                     int32_t*) {
-  (void)h;
-  return fail(PG_ERR_UNSUPPORTED, "MSA-1b Gibbs loop is not implemented in this build");
+
+int pg_msa_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int R, int C, const int32_t* target_idx, int n_iters,
+                     int P, const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
+  if (!h || !tokens_inout || (!target_idx && P > 0 && n_iters > 0)) return fail(PG_ERR_INVALID, "pg_msa_gibbs_run: null argument");
+  int rc = check_params(params);
+  if (rc) return rc;
+  if (B < 0 || R < 1 || C < 1 || P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "bad shape");
+  if (B == 0) return PG_OK;
+  Engine& e = h->e;
+  DeviceGuard g(e.device);
+  const size_t tok_bytes = (size_t)B * R * C * 4;
+  const size_t n_draws = (size_t)B * R * P * n_iters;
+  if ((rc = e.d_tokens.ensure(tok_bytes, e.stream))) return rc;
+  if ((rc = e.d_idx.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
+  if (sampled_logits && (rc = e.d_samp_logits.ensure((n_draws ? n_draws : 1) * e.cfg.vocab * 4, e.stream))) return rc;
+  if (sampled_tokens && (rc = e.d_samp_tok.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
+  PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens_inout, tok_bytes, hipMemcpyHostToDevice, e.stream));
+  if (n_draws) PG_HIP(hipMemcpyAsync(e.d_idx.p, target_idx, n_draws * 4, hipMemcpyHostToDevice, e.stream));
+  rc = e.msa_gibbs_device(e.d_tokens.as<int32_t>(), B, R, C, e.d_idx.as<int32_t>(), n_iters, P, params,
+                          sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
+                          sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
+  if (rc) return rc;
+  PG_HIP(hipMemcpyAsync(tokens_inout, e.d_tokens.p, tok_bytes, hipMemcpyDeviceToHost, e.stream));
+  if (sampled_logits && n_draws)
+    PG_HIP(hipMemcpyAsync(sampled_logits, e.d_samp_logits.p, n_draws * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
+  if (sampled_tokens && n_draws)
+    PG_HIP(hipMemcpyAsync(sampled_tokens, e.d_samp_tok.p, n_draws * 4, hipMemcpyDeviceToHost, e.stream));
+  PG_HIP(hipStreamSynchronize(e.stream));
+  return PG_OK;
 }
-int pg_msa_gibbs_single_run(pg_engine* h, int32_t*, int, int, int, int, const int32_t*, const int32_t*, int, int,
-                            const pg_sample_params*, float*, int32_t*) {
-  (void)h;
-  return fail(PG_ERR_UNSUPPORTED, "MSA-1b single-row Gibbs loop is not implemented in this build");
+
+int pg_msa_gibbs_single_run(pg_engine* h, int32_t* tokens_inout, int R, int C, int mask_row, int target_row,
+                            const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
+                            const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
+  if (!h || !tokens_inout || (n_steps > 0 && (!step_sample_flag || (!step_idx && P_max > 0))))
+    return fail(PG_ERR_INVALID, "pg_msa_gibbs_single_run: null argument");
+  int rc = check_params(params);
+  if (rc) return rc;
+  if (R < 1 || C < 1 || P_max < 0 || n_steps < 0) return fail(PG_ERR_INVALID, "bad shape");
+  Engine& e = h->e;
+  DeviceGuard g(e.device);
+  const size_t tok_bytes = (size_t)R * C * 4;
+  const size_t n_draws = (size_t)P_max * n_steps;
+  if ((rc = e.d_tokens.ensure(tok_bytes, e.stream))) return rc;
+  if ((rc = e.d_idx.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
+  if (sampled_logits && (rc = e.d_samp_logits.ensure((n_draws ? n_draws : 1) * e.cfg.vocab * 4, e.stream))) return rc;
+  if (sampled_tokens && (rc = e.d_samp_tok.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
+  PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens_inout, tok_bytes, hipMemcpyHostToDevice, e.stream));
+  if (n_draws) PG_HIP(hipMemcpyAsync(e.d_idx.p, step_idx, n_draws * 4, hipMemcpyHostToDevice, e.stream));
+  rc = e.msa_single_device(e.d_tokens.as<int32_t>(), R, C, mask_row, target_row, e.d_idx.as<int32_t>(), step_sample_flag,
+                           n_steps, P_max, params, sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
+                           sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
+  if (rc) return rc;
+  PG_HIP(hipMemcpyAsync(tokens_inout, e.d_tokens.p, tok_bytes, hipMemcpyDeviceToHost, e.stream));
+  if (sampled_logits && n_draws)
+    PG_HIP(hipMemcpyAsync(sampled_logits, e.d_samp_logits.p, n_draws * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
+  if (sampled_tokens && n_draws)
+    PG_HIP(hipMemcpyAsync(sampled_tokens, e.d_samp_tok.p, n_draws * 4, hipMemcpyDeviceToHost, e.stream));
+  PG_HIP(hipStreamSynchronize(e.stream));
+  return PG_OK;
+}
+
+int pg_msa_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int R, int C, const int32_t* d_target_idx,
+                            int n_iters, int P, const pg_sample_params* params, float* d_sampled_logits,
+                            int32_t* d_sampled_tokens) {
+  if (!h || !d_tokens_inout || (!d_target_idx && P > 0 && n_iters > 0))
+    return fail(PG_ERR_INVALID, "pg_msa_gibbs_run_device: null argument");
+  int rc = check_params(params);
+  if (rc) return rc;
+  DeviceGuard g(h->e.device);
+  return h->e.msa_gibbs_device(d_tokens_inout, B, R, C, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
 }
 
 // ---- stand-alone ends of the iteration ---------------------------------------------------------
@@ -256,6 +332,42 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
   return PG_OK;
 }
 
+int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int iters, double* avg_ms) {
+  if (!avg_ms || M % 256 || N % 128 || K % 64 || iters < 1) return fail(PG_ERR_INVALID, "pg_dbg_gemm_bench: bad argument");
+  DeviceGuard g(-1);
+  int rc = dbg_device(device);
+  if (rc) return rc;
+  Tmp t;
+  float* f = (float*)t.get((size_t)(M > N ? M : N) * K * 4);
+  bf16_t* bx = (bf16_t*)t.get((size_t)M * K * 2);
+  bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2);
+  float* db = (float*)t.get((size_t)N * 4);
+  void* dout = t.get((size_t)M * N * 4);
+  if (!f || !bx || !bw || !db || !dout) return fail(PG_ERR_HIP, "hipMalloc failed");
+  std::vector<float> h((size_t)(M > N ? M : N) * K);
+  uint32_t st = 12345u;
+  for (auto& v : h) { st = st * 1664525u + 1013904223u; v = ((st >> 8) * (1.0f / 8388608.0f) - 1.0f); }   // uniform [-1,1)
+  PG_HIP(hipMemcpy(f, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, f, bx, (int64_t)M * K, 1.f))) return rc;
+  if ((rc = launch_f32_to_bf16(nullptr, f, bw, (int64_t)N * K, 0.05f))) return rc;
+  hipEvent_t a, b;
+  PG_HIP(hipEventCreate(&a));
+  PG_HIP(hipEventCreate(&b));
+  for (int i = 0; i < 2; ++i)
+    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant))) return rc;
+  PG_HIP(hipEventRecord(a, nullptr));
+  for (int i = 0; i < iters; ++i)
+    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant))) return rc;
+  PG_HIP(hipEventRecord(b, nullptr));
+  PG_HIP(hipEventSynchronize(b));
+  float ms = 0;
+  PG_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *avg_ms = ms / iters;
+  return PG_OK;
+}
+
 int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps) {
   if (!x || !gamma || !beta || !y || M < 1 || d < 4) return fail(PG_ERR_INVALID, "pg_dbg_layernorm: bad argument");
   DeviceGuard g(-1);
@@ -293,6 +405,35 @@ int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, in
   PG_HIP(hipMemcpy(dq, qkv, (size_t)M * 3 * d * 4, hipMemcpyHostToDevice));
   if ((rc = launch_f32_to_bf16(nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
   if ((rc = launch_attention_bf16(nullptr, bq, bc, B, T, H, 3 * d, d, d, 2 * d))) return rc;
+  if ((rc = launch_bf16_to_f32(nullptr, bc, dc, M * d))) return rc;
+  PG_HIP(hipDeviceSynchronize());
+  PG_HIP(hipMemcpy(ctx, dc, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+  return PG_OK;
+}
+
+/* MSA attention blocks on fp32 host buffers qkv[B][R][C][3*H*64] -> ctx[B][R][C][H*64]; which: 0 = tied row attention
+ * (scores scaled by `scale`), 1 = column attention (q already scaled) */
+int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, int B, int R, int C, int H, float scale) {
+  if (!qkv || !ctx || B < 1 || R < 1 || C < 1 || H < 1) return fail(PG_ERR_INVALID, "pg_dbg_msa_attention: bad argument");
+  DeviceGuard g(-1);
+  int rc = dbg_device(device);
+  if (rc) return rc;
+  const int d = H * 64;
+  const int64_t M = (int64_t)B * R * C;
+  Tmp t;
+  float* dq = (float*)t.get((size_t)M * 3 * d * 4);
+  bf16_t* bq = (bf16_t*)t.get((size_t)M * 3 * d * 2);
+  bf16_t* bc = (bf16_t*)t.get((size_t)M * d * 2);
+  float* dc = (float*)t.get((size_t)M * d * 4);
+  if (!dq || !bq || !bc || !dc) return fail(PG_ERR_HIP, "hipMalloc failed");
+  PG_HIP(hipMemcpy(dq, qkv, (size_t)M * 3 * d * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
+  if (which == 0) {
+    if ((rc = launch_msa_row_attention_bf16(nullptr, bq, bc, B, R, C, H, 3 * d, d, d, 2 * d, scale))) return rc;
+  } else {
+    SeqLayout col = {C, R * C, 1, C};
+    if ((rc = launch_attention_seq_bf16(nullptr, bq, bc, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col))) return rc;
+  }
   if ((rc = launch_bf16_to_f32(nullptr, bc, dc, M * d))) return rc;
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(ctx, dc, (size_t)M * d * 4, hipMemcpyDeviceToHost));

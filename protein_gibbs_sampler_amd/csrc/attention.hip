@@ -25,15 +25,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // T > 16*(MAXKB-6), so only the last 6 blocks can hold masked (>= T) keys.
 template <int MAXKB>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
-                                                       int H, int ld_qkv, int ld_ctx, int k_off, int v_off) {
+                                                       int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
+                                                       SeqLayout sl) {
   constexpr int VT_LD = MAXKB * 16 + 8;  // bf16 elements per V^T row (592 B at MAXKB=18: conflict-free b64 reads)
   __shared__ __attribute__((aligned(16))) char smem[MAXKB * 16 * 128 + 64 * VT_LD * 2];
   char* Ks = smem;
   bf16_t* Vt = (bf16_t*)(smem + MAXKB * 16 * 128);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const bf16_t* base = qkv + (size_t)b * T * ld_qkv + h * 64;
+  // sequence `seq` = token rows row0 + t*row_step (ESM: contiguous rows of chain b; MSA column attention: the R rows
+  // of one column, C token-rows apart)
+  const int seq = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t row0 = (size_t)(seq / sl.inner_count) * sl.outer_rows + (size_t)(seq % sl.inner_count) * sl.inner_rows;
+  const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
+  const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
   // All MAXKB key blocks are computed unconditionally: K rows / V^T columns past T are zero-filled and
   // their scores are masked, so no wave-uniform branches (and no dynamic register indexing) are needed.
   constexpr int nkb = MAXKB;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
     // store: lane holds O[q = qb*16 + fr][d = db*16 + fq*4 + r]
     const int q = qb * 16 + fr;
     if (q < T) {
-      bf16_t* dst = ctx + ((size_t)b * T + q) * ld_ctx + h * 64 + fq * 4;
+      bf16_t* dst = ctx + row0 * ld_ctx_ + (size_t)q * ld_ctx + h * 64 + fq * 4;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 p;
@@ -146,11 +151,18 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
                           int k_off, int v_off) {
-  if (B == 0) return 0;
-  dim3 grid((unsigned)(B * H)), block(256);
+  SeqLayout sl = {1, T, 0, 1};
+  return launch_attention_seq_bf16(s, qkv, ctx, B, T, H, ld_qkv, ld_ctx, k_off, v_off, sl);
+}
+
+int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int64_t n_seq, int T, int H, int ld_qkv,
+                              int ld_ctx, int k_off, int v_off, SeqLayout sl) {
+  if (n_seq == 0) return 0;
+  if (n_seq * H > 0x7fffffff) return fail(1, "attention: too many sequences");
+  dim3 grid((unsigned)(n_seq * H)), block(256);
 #define PG_ATT(KB)                                                                                             \
   else if (T <= KB * 16) {                                                                                     \
-    hipLaunchKernelGGL(attention_kernel<KB>, grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off); \
+    hipLaunchKernelGGL(attention_kernel<KB>, grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl); \
   }
   if (T <= 0) return fail(1, "attention: empty sequence");
   PG_ATT(2) PG_ATT(4) PG_ATT(8) PG_ATT(12) PG_ATT(18) PG_ATT(24) PG_ATT(30) PG_ATT(36)

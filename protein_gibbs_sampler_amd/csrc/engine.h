@@ -73,6 +73,13 @@ struct Engine {
   int head(const int32_t* d_idx, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits);
   int esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp,
                        float* d_samp_logits, int32_t* d_samp_tok);
+  int msa_trunk(const int32_t* d_tok, int B, int R, int C);                  // tokens[B][R][C] -> x
+  int msa_gibbs_device(int32_t* d_tok, int B, int R, int C, const int32_t* d_idx, int n_iters, int P,
+                       const pg_sample_params* sp, float* d_samp_logits, int32_t* d_samp_tok);
+  // generate_single: B = 1; step s masks row mask_row and samples row target_row at d_step_idx[s][P_max]
+  int msa_single_device(int32_t* d_tok, int R, int C, int mask_row, int target_row, const int32_t* d_step_idx,
+                        const int32_t* step_sample_flag_host, int n_steps, int P_max, const pg_sample_params* sp,
+                        float* d_samp_logits, int32_t* d_samp_tok);
 
   // timing helper
   template <typename F> int timed(int cls, F&& f);

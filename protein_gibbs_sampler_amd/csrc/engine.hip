@@ -299,4 +299,117 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
   return PG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ESM-MSA-1b forward: tokens[B][R][C] -> x[B*R*C][d]
+// ------------------------------------------------------------------------------------------------
+int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C) {
+  const int d = cfg.d_model, f = cfg.d_ffn, H = cfg.n_heads;
+  const int64_t M = (int64_t)B * R * C;
+  const int64_t Mp = round_up64(M, kRowPad);
+  if (Mp > 0x7fffffff / 4) return fail(PG_ERR_INVALID, "too many tokens in one call");
+  int rc;
+  if ((rc = x.ensure((size_t)Mp * d * 4, stream))) return rc;
+  if ((rc = h.ensure((size_t)Mp * d * 2, stream))) return rc;
+  if ((rc = qkv.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;
+  if ((rc = ctx.ensure((size_t)Mp * d * 2, stream))) return rc;
+  if ((rc = ffn.ensure((size_t)Mp * f * 2, stream))) return rc;
+  float* X = x.as<float>();
+  bf16_t* Hh = h.as<bf16_t>();
+  bf16_t* QKV = qkv.as<bf16_t>();
+  bf16_t* CTX = ctx.as<bf16_t>();
+  bf16_t* FFN = ffn.as<bf16_t>();
+  const float eps = cfg.layer_norm_eps;
+  const int Mi = (int)Mp;
+  const float row_scale = 0.125f / sqrtf((float)R);      // dh^-0.5 / sqrt(R): depends on R, applied to the scores
+
+  rc = timed(PC_EMBED, [&] {
+    return launch_embed_ln(stream, d_tok, embed, pos, msa_pos, ln_before.g, ln_before.b, X, M, C, d, cfg.pad_idx,
+                           cfg.mask_idx, 0, R, eps);
+  });
+  if (rc) return rc;
+  const SeqLayout col = {C, R * C, 1, C};                   // column c of msa b: rows (b*R + r)*C + c
+  for (int l = 0; l < cfg.n_layers; ++l) {
+    const MsaLayer& L = msa_layers[l];
+    // tied row attention
+    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_row.g, L.ln_row.b, Hh, M, d, eps); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.row_out.w, L.row_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+    // column attention (q pre-scaled by dh^-0.5 in the weights)
+    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_col.g, L.ln_col.b, Hh, M, d, eps); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return launch_attention_seq_bf16(stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.col_out.w, L.col_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+    // feed forward
+    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_ffn.g, L.ln_ffn.b, Hh, M, d, eps); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID); }))) return rc;
+  }
+  return PG_OK;
+}
+
+static int check_msa_shape(const pg_model_config& cfg, int B, int R, int C) {
+  if (cfg.arch != PG_ARCH_MSA1B) return fail(PG_ERR_INVALID, "engine was not built for the MSA-1b architecture");
+  if (B < 0 || R < 1 || C < 1) return fail(PG_ERR_INVALID, "bad MSA shape");
+  if (R > cfg.max_msa_rows) return fail(PG_ERR_INVALID, "MSA has more rows than msa_position_embedding");
+  if (C > cfg.max_positions + 1) return fail(PG_ERR_INVALID, "alignment longer than the learned position table");
+  return PG_OK;
+}
+
+int Engine::msa_gibbs_device(int32_t* d_tok, int B, int R, int C, const int32_t* d_idx_, int n_iters, int P,
+                             const pg_sample_params* sp, float* d_samp_logits_, int32_t* d_samp_tok_) {
+  int rc = check_msa_shape(cfg, B, R, C);
+  if (rc) return rc;
+  if (P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "gibbs: negative size");
+  if (B == 0 || n_iters == 0) return PG_OK;
+  const int V = cfg.vocab;
+  const int64_t n_sel_rows = (int64_t)B * R;         // every row of every MSA draws its own P positions
+  const int64_t n_draws = n_sel_rows * P;
+  if (!d_samp_logits_ && (rc = logits.ensure((size_t)(n_draws > 0 ? n_draws : 1) * V * 4, stream))) return rc;
+  for (int it = 0; it < n_iters; ++it) {
+    const int32_t* idx_it = d_idx_ + (size_t)it * n_draws;
+    if (sp->mask && P > 0)
+      if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, C, idx_it, nullptr, n_sel_rows, P, sp->mask_idx); }))) return rc;
+    if ((rc = msa_trunk(d_tok, B, R, C))) return rc;
+    if (P == 0) continue;
+    float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)it * n_draws * V : logits.as<float>();
+    if ((rc = head(idx_it, nullptr, P, C, n_draws, lg))) return rc;
+    int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)it * n_draws : nullptr;
+    if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, it, st); }))) return rc;
+  }
+  return PG_OK;
+}
+
+int Engine::msa_single_device(int32_t* d_tok, int R, int C, int mask_row, int target_row, const int32_t* d_step_idx,
+                              const int32_t* step_sample_flag_host, int n_steps, int P_max, const pg_sample_params* sp,
+                              float* d_samp_logits_, int32_t* d_samp_tok_) {
+  int rc = check_msa_shape(cfg, 1, R, C);
+  if (rc) return rc;
+  if (mask_row < 0 || mask_row >= R || target_row < 0 || target_row >= R) return fail(PG_ERR_INVALID, "row index out of range");
+  if (P_max < 0 || n_steps < 0) return fail(PG_ERR_INVALID, "negative size");
+  if (n_steps == 0) return PG_OK;
+  const int V = cfg.vocab;
+  if ((rc = d_rowmap.ensure(8, stream))) return rc;
+  const int32_t maps[2] = {mask_row, target_row};
+  PG_HIP(hipMemcpyAsync(d_rowmap.p, maps, 8, hipMemcpyHostToDevice, stream));
+  PG_HIP(hipStreamSynchronize(stream));     // `maps` is a stack buffer
+  const int32_t* d_mask_map = d_rowmap.as<int32_t>();
+  const int32_t* d_tgt_map = d_rowmap.as<int32_t>() + 1;
+  if (!d_samp_logits_ && (rc = logits.ensure((size_t)(P_max > 0 ? P_max : 1) * V * 4, stream))) return rc;
+  pg_sample_params p = *sp;
+  for (int s = 0; s < n_steps; ++s) {
+    const int32_t* idx_s = d_step_idx + (size_t)s * P_max;
+    if (P_max > 0)   // generate_single always masks (esm_msa_sampler.py:133), row -1 regardless of the target row
+      if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, C, idx_s, d_mask_map, 1, P_max, sp->mask_idx); }))) return rc;
+    if ((rc = msa_trunk(d_tok, 1, R, C))) return rc;
+    if (P_max == 0) continue;
+    float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)s * P_max * V : logits.as<float>();
+    if ((rc = head(idx_s, d_tgt_map, P_max, C, P_max, lg))) return rc;
+    int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)s * P_max : nullptr;
+    p.burnin = step_sample_flag_host[s] ? 0x7fffffff : 0;   // sample=(pass_num < burn_in), esm_msa_sampler.py:143
+    if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg, V, 1, idx_s, d_tgt_map, 1, P_max, &p, s, st); }))) return rc;
+  }
+  return PG_OK;
+}
+
 }  // namespace pg

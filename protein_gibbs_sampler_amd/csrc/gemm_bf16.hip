@@ -17,6 +17,8 @@
 //     lane group touches 16 distinct 16-B slots (conflict-free).
 //   * 1-D grid remapped so each XCD (private L2) owns a contiguous range of tiles.
 //   * epilogues fused: +bias, erf-GELU, bf16 pack, fp32 residual read-modify-write.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace pg {
@@ -27,7 +29,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define PG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define PG_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU, branch-free: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. below bf16/fp32 noise of the
+// surrounding GEMM), one v_rcp + one v_exp instead of ocml's piecewise erff.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = 1.0f - p * t * __expf(-z * z);       // erf(|x|/sqrt2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;                 // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
+}
 
 // Stage ROWS x 64 bf16 (128 B per row) into LDS.  One wave-instruction = 8 rows = 1 KiB, written
 // lane-linearly; lane l covers row (l>>3), LDS chunk (l&7), which receives global chunk (l&7)^(row&7).
@@ -138,6 +152,227 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "Ping-pong" 256x256x64 kernel (the hot one).
+//
+// The 8 waves form two groups of four (waves w and w+4 share a SIMD).  Work on a K-tile is cut into
+// two half-steps (k 0..31 / 32..63); a wave alternates between an L segment (12 ds_read_b128 of the
+// next half-step's fragments + 4 LDS-DMA pieces of the NEXT K-tile) and a C segment (32 MFMAs), with a
+// raw s_barrier after every segment.  Group 1 executes one extra barrier up front, so its segments
+// are shifted by one: while one group's MFMAs own the matrix pipe, the other group is reading LDS and
+// issuing DMA.  DMA completion is a counted `s_waitcnt vmcnt(4)` (never 0 in steady state): a piece
+// issued in one L segment is only waited for at the end of the wave's next L segment, i.e. two barrier
+// intervals later.
+//
+// LDS: 4 half-buffers [tile parity][k half], each 256 X rows + 256 W rows of 64 B (32 bf16).
+// A half-buffer is rewritten (for tile t+1) only after both groups finished reading tile t-1 from it:
+//   piece (t+1, kk) is issued in L(t, kk);  last read of (t-1, kk) is group 1's L(t-1, kk), which ends
+//   at least one barrier earlier for every wave.
+// 16-B chunks are XOR-swizzled with pi[(row>>2)&3], pi = {0,3,2,1} (applied to the DMA source address
+// and to the ds_read address) so that every ds_read_b128 lane group hits 16 distinct 16-B slots.
+// ------------------------------------------------------------------------------------------------
+// ABL (micro-benchmark ablations only): 0 = real kernel, 1 = no LDS-DMA inside the K loop (tile 0 reused),
+// 2 = no MFMA (fragments kept alive), 3 = no ds_read (fragments loaded once)
+template <int EPI, int ABL = 0, int GM = 4>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                          const float* __restrict__ bias, void* __restrict__ out, int K,
+                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+  constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
+  __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2;                      // 0: leads, 1: lags by one barrier
+  const int wm = grp, wn = wave & 3;              // wave tile: rows wm*128.. of X, rows wn*64.. of W
+
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = n_tiles >> 3, r = n_tiles & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // grouped rasterisation inside the XCD's range: GM m-panels x all n-tiles per group, m fastest, so the ~32
+  // tiles an XCD runs concurrently form a GM x (32/GM) rectangle that shares X and W k-slices through its L2.
+  int tile_m, tile_n;
+  {
+    const int tiles_m = n_tiles / tiles_n;
+    const int gsz = GM * tiles_n, g = bid / gsz, within = bid - g * gsz;
+    const int rows = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
+    tile_m = g * GM + within % rows;
+    tile_n = within / rows;
+  }
+  const int m0 = tile_m * 256;
+  const int n0 = tile_n * 256;
+
+  // ---- LDS-DMA source addressing: wave stages pieces wave*4 .. wave*4+3 of the 32 pieces (16 rows each) of a
+  // half-tile; pieces 0-15 are X rows, 16-31 are W rows.  lane -> row (lane>>2), LDS chunk (lane&3).
+  const bool stage_w = wave >= 4;
+  const bf16_t* src = stage_w ? W : X;
+  const int lds_ = stage_w ? ldw : ldx;
+  const int srow0 = (stage_w ? n0 : m0) + (wave & 3) * 64 + (lane >> 2);
+  const int schunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);                 // pi[(row>>2)&3] = (-g)&3
+  const bf16_t* gsrc = src + (size_t)srow0 * lds_ + schunk * 8;            // + i*16 rows, + k
+  const size_t piece_stride = (size_t)16 * lds_;
+  const int lds_piece0 = (stage_w ? 256 * 64 : 0) + (wave & 3) * 4 * 1024;  // byte offset inside a half-buffer
+
+  auto stage_half = [&](int t, int kk) {
+    char* hb = smem + ((t & 1) * 2 + kk) * HALF_BYTES + lds_piece0;
+    const bf16_t* g = gsrc + (size_t)t * 64 + kk * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(PG_GLB_PTR(g + i * piece_stride), PG_LDS_PTR(hb + i * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / 64;
+  stage_half(0, 0);
+  stage_half(0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (grp == 1) __builtin_amdgcn_s_barrier();      // stagger the two groups by one barrier interval
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int foff = fr * 64 + ((fq ^ ((0 - (fr >> 2)) & 3)) << 4);          // row*64 + swizzled chunk*16
+  const int xoff = (wm * 128) * 64 + foff;
+  const int woff = 256 * 64 + (wn * 64) * 64 + foff;
+
+  bf16x8 wf[4], xf[8];
+  for (int t = 0; t < nk; ++t) {
+    const bool has_next = (t + 1 < nk);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      // ---------------- L segment: fragments of (t, kk) + DMA of (t+1, kk) ----------------
+      const char* hb = smem + (((ABL == 1 ? 0 : (t & 1)) * 2) + kk) * HALF_BYTES;
+      if (has_next && ABL != 1) stage_half(t + 1, kk);
+      if (ABL != 3 || t == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(hb + woff + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(hb + xoff + j * 1024);
+      }
+      if (has_next && ABL != 1) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the 4 pieces just issued
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- C segment: 32 MFMAs ----------------
+      __builtin_amdgcn_s_setprio(1);
+      if (ABL != 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(xf[j]));
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
+
+  // epilogue: lane holds D[n = nb + fq*4 + r][m = mb + fr]
+  if (EPI == EPI_F32_RESID) {
+    // fp32 residual stream read-modify-write.  x streams from HBM (it never fits a cache), so the loads are issued
+    // in two batches of 16 x 16 B per lane before any is consumed: 2 memory round trips instead of one per tile row.
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float4 r[2][8];
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int n = n0 + wn * 64 + (ih * 2 + i2) * 16 + fq * 4;
+          const int m = m0 + wm * 128 + j * 16 + fr;
+          r[i2][j] = *(const float4*)((const float*)out + (size_t)m * ldo + n);
+        }
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int i = ih * 2 + i2;
+        const int n = n0 + wn * 64 + i * 16 + fq * 4;
+        const float4 b4 = *(const float4*)(bias + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int m = m0 + wm * 128 + j * 16 + fr;
+          float4 v = r[i2][j];
+          v.x += acc[i][j][0] + b4.x; v.y += acc[i][j][1] + b4.y; v.z += acc[i][j][2] + b4.z; v.w += acc[i][j][3] + b4.w;
+          *(float4*)((float*)out + (size_t)m * ldo + n) = v;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wn * 64 + i * 16 + fq * 4;
+    const float4 b4 = *(const float4*)(bias + n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = m0 + wm * 128 + j * 16 + fr;
+      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+      if (EPI == EPI_BF16_GELU || EPI == EPI_F32_GELU) {
+        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+      }
+      if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+        uint2 p;
+        p.x = pack_bf16x2(v0, v1);
+        p.y = pack_bf16x2(v2, v3);
+        *(uint2*)((bf16_t*)out + (size_t)m * ldo + n) = p;
+      } else {
+        *(float4*)((float*)out + (size_t)m * ldo + n) = make_float4(v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
+static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
+                     int ldx, int ldw, int ldo, int epi, int abl = 0) {
+  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+  dim3 grid(n_tiles), block(512);
+  if (abl) {   // ablations: EPI_BF16 only
+    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    PG_HIP(hipGetLastError());
+    return 0;
+  }
+#define PG_GEMM_CASE(E)                                                                                        \
+  case E:                                                                                                      \
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, \
+                       n_tiles);                                                                               \
+    break;
+  switch (epi) {
+    PG_GEMM_CASE(EPI_BF16)
+    PG_GEMM_CASE(EPI_BF16_GELU)
+    PG_GEMM_CASE(EPI_F32_RESID)
+    PG_GEMM_CASE(EPI_F32)
+    PG_GEMM_CASE(EPI_F32_GELU)
+    default:
+      return fail(1, "gemm: bad epilogue");
+  }
+#undef PG_GEMM_CASE
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                       int K, int ldx, int ldw, int ldo, int epi) {
@@ -164,7 +399,15 @@ static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const flo
 
 int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi) {
+  static const int variant = [] { const char* e = getenv("PGIBBS_GEMM"); return e ? atoi(e) : 2; }();
+  return launch_gemm_bf16_variant(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant);
+}
+
+int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
+                             int K, int ldx, int ldw, int ldo, int epi, int variant) {
   if (M % 128 || N % 128 || K % 64) return fail(1, "gemm: M,N must be multiples of 128 and K of 64");
+  if (M % 256 == 0 && N % 256 == 0 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
+  if (M % 256 == 0 && N % 256 == 0 && variant >= 2) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (M % 256 == 0 && N % 256 == 0) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }

@@ -11,10 +11,21 @@ enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_
 // out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M, N multiples of 128, K of 64 (buffers are row-padded).
 int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi);
+// variant: 1 = lockstep double-buffered kernel, 2 = ping-pong kernel (default), used by the micro-benchmark entry
+int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
+                             int K, int ldx, int ldw, int ldo, int epi, int variant);
 
 // fused attention, one (sequence, head) per workgroup; qkv rows are [q | k | v] with head h at h*64
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
                           int k_off, int v_off);
+// same kernel over strided sequences: sequence s covers token rows
+//   (s / inner_count) * outer_rows + (s % inner_count) * inner_rows + t * row_step,  t = 0..T-1
+struct SeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
+int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int64_t n_seq, int T, int H, int ld_qkv,
+                              int ld_ctx, int k_off, int v_off, SeqLayout sl);
+// MSA tied row attention: one C x C map per (msa, head) from scores summed over the R rows
+int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
+                                  int ld_ctx, int k_off, int v_off, float scale);
 
 int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,

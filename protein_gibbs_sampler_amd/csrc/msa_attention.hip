@@ -1,0 +1,171 @@
+// Tied row attention of the MSA Transformer (fair-esm RowSelfAttention), reached by the reference
+// through `self.model.model(batch)["logits"]` (/root/reference/src/pgen/esm_msa_sampler.py:136,236):
+//   A[h,i,j] = scale * sum_r sum_d q[r,i,h,d] k[r,j,h,d]      (scale = 64^-0.5 / sqrt(R), one map per head for ALL rows)
+//   P = softmax_j(A);   ctx[r,i,h,:] = sum_j P[h,i,j] v[r,j,h,:]
+// (Column attention is the plain fused attention kernel over strided sequences: attention.hip.)
+//
+// One workgroup = (msa b, head h, 64 queries); wave w owns 16 of them.  Pass 1 streams K_r (C x 64) through LDS for
+// r = 0..R-1 and accumulates the S^T blocks of the wave's 16 queries in registers with v_mfma_f32_16x16x32_bf16
+// (the same lane-local layout as attention.hip: a lane holds one query's scores for 4 keys of every 16-key block),
+// then one exact softmax; pass 2 streams V_r^T through LDS and emits ctx for every row with the same P fragments.
+#include "kernels.h"
+
+namespace pg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int MAXKB>
+__global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int R, int C, int H, int ld_qkv, int ld_ctx, int k_off,
+    int v_off, float scale, int n_qblk) {
+  constexpr int VT_LD = MAXKB * 16 + 8;
+  constexpr int tpad = MAXKB * 16;
+  __shared__ __attribute__((aligned(16))) char smem[MAXKB * 16 * 128 + 64 * VT_LD * 2];
+  char* Ks = smem;
+  bf16_t* Vt = (bf16_t*)(smem + MAXKB * 16 * 128);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qblk = blockIdx.x % n_qblk, bh = blockIdx.x / n_qblk;
+  const int b = bh / H, h = bh % H;
+  const bf16_t* base = qkv + (size_t)b * R * C * ld_qkv + h * 64;   // row (r*C + i)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int q0 = qblk * 64 + wave * 16;
+  const bool active = q0 < C;                                      // wave-uniform
+  int qrow = q0 + fr;
+  if (qrow >= C) qrow = C - 1;
+
+  f32x4 st[MAXKB];
+#pragma unroll
+  for (int kb = 0; kb < MAXKB; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- pass 1: scores summed over rows ------------------------------------------------------
+  for (int r = 0; r < R; ++r) {
+    const bf16_t* rb = base + (size_t)r * C * ld_qkv;
+    __syncthreads();
+    for (int i = tid; i < tpad * 8; i += 256) {
+      const int row = i >> 3, c = i & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < C) v = *(const uint4*)(rb + (size_t)row * ld_qkv + k_off + c * 8);
+      *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    }
+    __syncthreads();
+    if (active) {
+      bf16x8 qf[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(rb + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
+#pragma unroll
+      for (int kb = 0; kb < MAXKB; ++kb) {
+        const int krow = kb * 16 + fr;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
+          st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- softmax over keys ---------------------------------------------------------------------
+  float mx = -3.0e38f;
+  int tl = C - fq * 4;
+#pragma unroll
+  for (int kb = 0; kb < MAXKB; ++kb) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      st[kb][r4] *= scale;
+      if (kb >= MAXKB - 6 && kb * 16 + r4 >= tl) st[kb][r4] = -3.0e38f;
+      mx = fmaxf(mx, st[kb][r4]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < MAXKB; ++kb) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const float e = __expf(st[kb][r4] - mx);
+      st[kb][r4] = e;
+      sum += e;
+    }
+  }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  union PF { bf16x8 v; uint32_t u[4]; };
+  PF pf[MAXKB / 2];
+#pragma unroll
+  for (int c = 0; c < MAXKB / 2; ++c) {
+    const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
+    pf[c].u[0] = pack_bf16x2(lo[0] * inv, lo[1] * inv);
+    pf[c].u[1] = pack_bf16x2(lo[2] * inv, lo[3] * inv);
+    pf[c].u[2] = pack_bf16x2(hi[0] * inv, hi[1] * inv);
+    pf[c].u[3] = pack_bf16x2(hi[2] * inv, hi[3] * inv);
+  }
+
+  // ---- pass 2: ctx[r] = P . V_r for every row ------------------------------------------------
+  for (int r = 0; r < R; ++r) {
+    const bf16_t* rb = base + (size_t)r * C * ld_qkv;
+    __syncthreads();
+    for (int i = tid; i < tpad * 8; i += 256) {
+      const int key = i % tpad, c = i / tpad;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (key < C) v = *(const uint4*)(rb + (size_t)key * ld_qkv + v_off + c * 8);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VT_LD + key] = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+    }
+    __syncthreads();
+    if (active) {
+      f32x4 o[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < MAXKB / 2; ++c) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          union { bf16x8 v; uint2 h2[2]; } vf;
+          const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
+          vf.h2[0] = *(const uint2*)(vrow);
+          vf.h2[1] = *(const uint2*)(vrow + 16);
+          o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[c].v, o[db], 0, 0, 0);
+        }
+      }
+      const int q = q0 + fr;
+      if (q < C) {
+        bf16_t* dst = ctx + ((size_t)(b * R + r) * C + q) * ld_ctx + h * 64 + fq * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          uint2 p;
+          p.x = pack_bf16x2(o[db][0], o[db][1]);
+          p.y = pack_bf16x2(o[db][2], o[db][3]);
+          *(uint2*)(dst + db * 16) = p;
+        }
+      }
+    }
+  }
+}
+
+int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
+                                  int ld_ctx, int k_off, int v_off, float scale) {
+  if (B == 0 || R == 0) return 0;
+  if (C <= 0) return fail(1, "row attention: empty alignment");
+  const int n_qblk = (C + 63) / 64;
+  dim3 grid((unsigned)(B * H * n_qblk)), block(256);
+#define PG_ROWATT(KB)                                                                                                  \
+  else if (C <= KB * 16) {                                                                                             \
+    hipLaunchKernelGGL(msa_row_attention_kernel<KB>, grid, block, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx, k_off, v_off, \
+                       scale, n_qblk);                                                                                 \
+  }
+  if (false) {}
+  PG_ROWATT(2) PG_ROWATT(4) PG_ROWATT(8) PG_ROWATT(12) PG_ROWATT(18) PG_ROWATT(24) PG_ROWATT(30) PG_ROWATT(36)
+#undef PG_ROWATT
+  else {
+    return fail(5, "row attention: alignments wider than 575 columns are not supported yet");
+  }
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace pg

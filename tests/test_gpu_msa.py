@@ -1,0 +1,146 @@
+"""ESM-MSA-1b path on the MI355X against the CPU oracle: the two axial-attention kernels, the whole
+forward (logits), and the Gibbs loops of ESM_MSA_sampler.generate / generate_single with every draw
+replayed by the oracle from the logits the engine emitted."""
+import random
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import draw as odraw
+from oracle.msa_forward import MsaConfig, msa_forward, synthetic_msa_weights
+from protein_gibbs_sampler_amd import _lib, esm_msa_sampler, models, weights
+from test_gpu_kernels import _bf16
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = 0.15
+
+
+@pytest.mark.parametrize("B,R,C,H", [(2, 3, 20, 2), (1, 32, 257, 2), (2, 5, 70, 1), (1, 8, 130, 3), (1, 2, 300, 1)])
+def test_row_attention_kernel(B, R, C, H):
+    rng = np.random.default_rng(C)
+    d = H * 64
+    qkv = rng.standard_normal((B, R, C, 3 * d), dtype=np.float32)
+    scale = np.float32(0.125 / np.sqrt(R))
+    ctx = np.empty((B, R, C, d), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_msa_attention(0, 0, _lib.ptr(qkv), _lib.ptr(ctx), B, R, C, H, float(scale)))
+    r = _bf16(qkv).astype(np.float64)
+    q, k, v = (r[..., i * d:(i + 1) * d].reshape(B, R, C, H, 64) for i in range(3))
+    a = np.einsum("brihd,brjhd->bhij", q, k) * float(scale)
+    p = np.exp(a - a.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhij,brjhd->brihd", p, v).reshape(B, R, C, d)
+    assert np.abs(ctx - ref).max() < 2.5e-2 and np.abs(ctx - ref).mean() < 3e-3
+
+
+@pytest.mark.parametrize("B,R,C,H", [(2, 3, 20, 2), (1, 32, 50, 2), (1, 128, 9, 1), (2, 1, 12, 1), (1, 17, 33, 3)])
+def test_column_attention_kernel(B, R, C, H):
+    rng = np.random.default_rng(R)
+    d = H * 64
+    qkv = rng.standard_normal((B, R, C, 3 * d), dtype=np.float32)
+    qkv[..., :d] *= 0.35
+    ctx = np.empty((B, R, C, d), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_msa_attention(0, 1, _lib.ptr(qkv), _lib.ptr(ctx), B, R, C, H, 1.0))
+    r = _bf16(qkv).astype(np.float64)
+    q, k, v = (r[..., i * d:(i + 1) * d].reshape(B, R, C, H, 64) for i in range(3))
+    a = np.einsum("bichd,bjchd->bhcij", q, k)
+    p = np.exp(a - a.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhcij,bjchd->bichd", p, v).reshape(B, R, C, d)
+    assert np.abs(ctx - ref).max() < 2.5e-2 and np.abs(ctx - ref).mean() < 3e-3
+
+
+CK = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=80, max_rows=16)
+
+
+def _model(sd, ck=CK):
+    cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=ck["d_model"], n_layers=ck["n_layers"], d_ffn=ck["d_ffn"],
+                              max_positions=ck["max_pos"], max_msa_rows=ck["max_rows"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return models.ESM_MSA1(state_dict=sd, config=cfg)
+
+
+def test_msa_forward_logits_vs_oracle():
+    ocfg = MsaConfig(**CK)
+    sd = synthetic_msa_weights(ocfg, seed=4, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    m = _model(sd).model.to("cuda:0")
+    rng = np.random.default_rng(1)
+    for (B, R, C) in [(2, 4, 21), (1, 7, 66), (3, 1, 10)]:
+        tok = rng.integers(4, 24, (B, R, C))
+        tok[rng.random((B, R, C)) < 0.1] = 30
+        tok[rng.random((B, R, C)) < 0.1] = 32
+        tok[..., 0] = 0
+        got = m.forward_logits(tok)
+        want = msa_forward(sd, ocfg, tok)
+        err = np.abs(got - want).max()
+        print("\nMSA forward %s: max|engine - oracle| = %.3e (logit std %.2f), argmax agreement %.4f"
+              % ((B, R, C), err, want.std(), (got.argmax(-1) == want.argmax(-1)).mean()))
+        assert err < BF16_TOL
+
+
+def test_msa_generate_draws_replay_exactly():
+    ocfg = MsaConfig(**CK)
+    sd = synthetic_msa_weights(ocfg, seed=6, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    s = esm_msa_sampler.ESM_MSA_sampler(_model(sd), device="gpu")
+    s.draw_seed, s.record = 7, True
+    msa = ["MEPAATGQEAEECAHSGRGEAW", "MEP-ATGQEAEECAHSG-GEAW", "MKPAATGQ--EECAHSGRGEAV"]
+    L, R, B, P, iters = len(msa[0]), 3, 2, 4, 3
+    random.seed(11)
+    out = s.generate(2 * R * B, msa, batch_size=B, num_iters=iters, num_positions=P, top_k=3, burnin=1, temperature=0.8,
+                     show_progress_bar=False)
+    assert len(out) == 2 * R * B and all(len(x) == L for x in out)
+    random.seed(11)
+    for rnd, run in enumerate(s.last_run):
+        table = np.asarray([[[random.sample(range(1, L + 1), P) for _ in range(R)] for _ in range(B)] for _ in range(iters)])
+        assert (run["table"] == table).all()
+        tok = s.get_init_msa(msa, L, B).numpy().astype(np.int32)
+        for it in range(iters):
+            rows = run["sampled_logits"][it].reshape(-1, 33)
+            rid = rnd * B * R + np.repeat(np.arange(B * R), P)
+            want = odraw.draw_rows(rows, s.valid_aa_idx, 3, it < 1, 0.8, rid, it, np.tile(np.arange(P), B * R), 0, 7).reshape(B, R, P)
+            assert (want == run["sampled_tokens"][it]).all()
+            tin = tok.copy()
+            for b in range(B):
+                for r in range(R):
+                    tin[b, r, table[it, b, r]] = 32
+            ref = msa_forward(sd, ocfg, tin)
+            ref_rows = np.stack([ref[b, r, table[it, b, r]] for b in range(B) for r in range(R)]).reshape(-1, 33)
+            assert np.abs(rows - ref_rows).max() < BF16_TOL
+            for b in range(B):
+                for r in range(R):
+                    tok[b, r, table[it, b, r]] = want[b, r]
+        assert (tok == run["tokens"]).all()
+
+
+@pytest.mark.parametrize("target_index", [0, -1, 1])
+def test_msa_generate_single_native(target_index):
+    ocfg = MsaConfig(**CK)
+    sd = synthetic_msa_weights(ocfg, seed=8, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    s = esm_msa_sampler.ESM_MSA_sampler(_model(sd), device="cuda:0")
+    s.draw_seed, s.record = 3, True
+    msa = ["ACDEFGHIKLMNPQ", "ACDEFGHIKLMNPQ", "AC-EFGHIKLMNPV"]
+    L, R = len(msa[0]), 3
+    random.seed(2)
+    out = s.generate_single(msa, steps=4, passes=2, burn_in=1, target_index=target_index, k=1, exclude_positions=[0, 5])
+    run = s.last_run[0]
+    # host control logic: shuffle + partition exactly as the reference (esm_msa_sampler.py:119-131)
+    random.seed(2)
+    positions = [p for p in range(1, L + 1) if p not in (1, 6)]
+    steps = []
+    for _ in range(2):
+        random.shuffle(positions)
+        steps += esm_msa_sampler.partition(positions, 4)
+    tr = target_index % R
+    tok = s.get_init_msa(msa, L, 1).numpy().astype(np.int32)
+    for i, st in enumerate(steps):
+        assert run["table"][i, 0, :len(st)].tolist() == st and (run["table"][i, 0, len(st):] == -1).all()
+        tok[0, R - 1, st] = 32                                   # quirk Q2: row -1 is the one masked
+        rows = run["sampled_logits"][i][:len(st)]
+        ref = msa_forward(sd, ocfg, tok)[0, tr, st]
+        assert np.abs(rows - ref).max() < BF16_TOL
+        want = odraw.draw_rows(rows, s.valid_aa_idx, 1, i < 4, None, [tr] * len(st), i, np.arange(len(st)), 0, 3)
+        assert (want == run["sampled_tokens"][i][:len(st)]).all()
+        tok[0, tr, st] = want
+    assert (tok == run["tokens"]).all()
+    assert out == s.untokenize_batch(tok)[target_index]
