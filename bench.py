@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from protein_gibbs_sampler_amd import _lib, models, pyrandom, weights  # noqa: E402
+from protein_gibbs_sampler_amd import _lib, models, pyrandom, sharding, weights  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -127,7 +127,7 @@ def main():
     aa = rng.integers(0, 20, (B_total, L))
     tok_all = np.concatenate([np.zeros((B_total, 1), np.int64), np.asarray(valid_idx)[aa], np.full((B_total, 1), 2)], axis=1)
     tok_dev = torch.from_numpy(tok_all[rank * B:(rank + 1) * B].astype(np.int32)).to(dev).contiguous()
-    gathered = torch.empty((B_total, T), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = None
 
     pos_rng = pyrandom.NativePyRandom()
     pos_rng.seed(0)
@@ -139,8 +139,8 @@ def main():
 
     def run(n_iters, iter_base):
         """n_iters Gibbs iterations: native position table for ALL chains (same stream on every rank), slice, upload, run."""
-        table = pos_rng.sample_table(population, P, n_iters * B_total).reshape(n_iters, B_total, P)
-        d_idx = torch.from_numpy(np.ascontiguousarray(table[:, rank * B:(rank + 1) * B])).to(dev, non_blocking=True)
+        table = sharding.global_position_table(pos_rng, population, P, n_iters, B_total)
+        d_idx = torch.from_numpy(sharding.local_slice(table, rank * B, (rank + 1) * B)).to(dev, non_blocking=True)
         params.iter_base = iter_base
         _lib.check(L_.pg_esm_gibbs_run_device(lm.handle, ctypes.c_void_p(tok_dev.data_ptr()), B, T,
                                               ctypes.c_void_p(d_idx.data_ptr()), n_iters, P, ctypes.byref(params), None, None))
@@ -158,7 +158,7 @@ def main():
     keep = run(K, W)                                                   # noqa: F841 (keeps the index table alive)
     if dist is not None:
         lm.synchronize()                                               # engine stream -> before the collective reads tokens
-        dist.all_gather_into_tensor(gathered, tok_dev)                 # the one collective: final token buffers
+        gathered = sharding.gather_tokens(dist, tok_dev)               # the one collective: final token buffers
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
