@@ -55,7 +55,9 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[kMaxCh], int nch4, int la
     }
 }
 
-__device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane) {
+// hi = bf16(v); optional lo = bf16(v - hi): the split-bf16 ("bf16x3") operand pair of the strict precision mode
+__device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane,
+                                               bf16_t* dst_lo = nullptr) {
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) {
@@ -63,6 +65,12 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kM
       p.x = pack_bf16x2(v[i].x, v[i].y);
       p.y = pack_bf16x2(v[i].z, v[i].w);
       ((uint2*)dst)[lane + 64 * i] = p;
+      if (dst_lo) {
+        uint2 q;
+        q.x = pack_bf16x2(v[i].x - bf16_to_f32((bf16_t)(p.x & 0xffff)), v[i].y - bf16_to_f32((bf16_t)(p.x >> 16)));
+        q.y = pack_bf16x2(v[i].z - bf16_to_f32((bf16_t)(p.y & 0xffff)), v[i].w - bf16_to_f32((bf16_t)(p.y >> 16)));
+        ((uint2*)dst_lo)[lane + 64 * i] = q;
+      }
     }
 }
 
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
 // ---- LayerNorm: x fp32 [M][d] -> h bf16 [M][d] ------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ h,
-                                                            int64_t M, int d, float eps) {
+                                                            bf16_t* __restrict__ h_lo, int64_t M, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
   ln_inplace(v, nch4, lane, d, eps, gamma, beta);
-  store_row_bf16(h + (size_t)row * d, v, nch4, lane);
+  store_row_bf16(h + (size_t)row * d, v, nch4, lane, h_lo ? h_lo + (size_t)row * d : nullptr);
 }
 
 // fp32 -> fp32 LayerNorm (debug entry / strict paths)
@@ -166,7 +174,8 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
 __global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                             const int32_t* __restrict__ row_map, int P, int width,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            bf16_t* __restrict__ h, int64_t n_sel, int d, float eps) {
+                                                            bf16_t* __restrict__ h, bf16_t* __restrict__ h_lo, int64_t n_sel,
+                                                            int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_sel) return;
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __rest
       if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
     ln_inplace(v, nch4, lane, d, eps, gamma, beta);
   }
-  store_row_bf16(h + (size_t)r * d, v, nch4, lane);
+  store_row_bf16(h + (size_t)r * d, v, nch4, lane, h_lo ? h_lo + (size_t)r * d : nullptr);
 }
 
 // ---- LM-head tail: logits[r][V] = LN(g[r]) . embed^T + bias ----------------------------------
@@ -226,6 +235,33 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(const float* __restrict__ 
   if (lane < V) logits[(size_t)r * V + lane] = mine;
 }
 
+// ---- strict mode helpers: fp32 -> (hi, lo) bf16 pair, optionally through erf-GELU ----------------
+__device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <bool GELU>
+__global__ void split_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n4,
+                                  float scale) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    float4 v = ((const float4*)src)[i];
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    if (GELU) { v.x = gelu_erf_exact(v.x); v.y = gelu_erf_exact(v.y); v.z = gelu_erf_exact(v.z); v.w = gelu_erf_exact(v.w); }
+    uint2 p, q;
+    p.x = pack_bf16x2(v.x, v.y);
+    p.y = pack_bf16x2(v.z, v.w);
+    q.x = pack_bf16x2(v.x - bf16_to_f32((bf16_t)(p.x & 0xffff)), v.y - bf16_to_f32((bf16_t)(p.x >> 16)));
+    q.y = pack_bf16x2(v.z - bf16_to_f32((bf16_t)(p.y & 0xffff)), v.w - bf16_to_f32((bf16_t)(p.y >> 16)));
+    ((uint2*)hi)[i] = p;
+    ((uint2*)lo)[i] = q;
+  }
+}
+__global__ void gelu_f32_kernel(float* __restrict__ p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = gelu_erf_exact(p[i]);
+}
+
 // ---- fp32 <-> bf16 conversion (weights at load time, debug entries) ---------------------------
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,10 +294,10 @@ int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, co
 }
 
 int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
-                          int d, float eps) {
+                          int d, float eps, bf16_t* h_lo) {
   if (d % 4 || d > kMaxCh * 256) return fail(1, "layernorm: d must be a multiple of 4 and <= 2048");
   if (M == 0) return 0;
-  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, M, d, eps);
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, h_lo, M, d, eps);
   PG_HIP(hipGetLastError());
   return 0;
 }
@@ -276,10 +312,10 @@ int launch_layernorm_f32(hipStream_t s, const float* x, const float* gamma, cons
 }
 
 int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, const int32_t* row_map, int P, int width,
-                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps) {
+                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps, bf16_t* h_lo) {
   if (n_sel == 0) return 0;
   hipLaunchKernelGGL(gather_ln_bf16_kernel, dim3(rows_grid(n_sel)), dim3(256), 0, s, x, idx, row_map, P, width, gamma,
-                     beta, h, n_sel, d, eps);
+                     beta, h, h_lo, n_sel, d, eps);
   PG_HIP(hipGetLastError());
   return 0;
 }
@@ -290,6 +326,24 @@ int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const floa
   if (n == 0) return 0;
   hipLaunchKernelGGL(lm_tail_kernel, dim3(rows_grid(n)), dim3(256), 0, s, g, gamma, beta, embed, out_bias, logits, n, d, V,
                      eps);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_split_bf16(hipStream_t s, const float* src, bf16_t* hi, bf16_t* lo, int64_t n, float scale, bool gelu) {
+  if (n == 0) return 0;
+  if (n % 4) return fail(1, "split: n must be a multiple of 4");
+  const int64_t n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  if (gelu) hipLaunchKernelGGL(split_bf16_kernel<true>, dim3(grid), dim3(256), 0, s, src, hi, lo, n4, scale);
+  else hipLaunchKernelGGL(split_bf16_kernel<false>, dim3(grid), dim3(256), 0, s, src, hi, lo, n4, scale);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+int launch_gelu_f32(hipStream_t s, float* p, int64_t n) {
+  if (n == 0) return 0;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gelu_f32_kernel, dim3(grid), dim3(256), 0, s, p, n);
   PG_HIP(hipGetLastError());
   return 0;
 }

@@ -30,8 +30,9 @@ struct Prof {
 
 enum ProfClass { PC_GEMM = 0, PC_ATTN, PC_LN, PC_EMBED, PC_HEAD, PC_SAMPLE, PC_COUNT };
 
-struct DenseW {   // y = x W^T + b ; W bf16 [N][K], b fp32 [N]
+struct DenseW {   // y = x W^T + b ; W bf16 [N][K], b fp32 [N]; w_lo = bf16(W - w) in the strict precision mode
   bf16_t* w = nullptr;
+  bf16_t* w_lo = nullptr;
   float* b = nullptr;
   int N = 0, K = 0;
 };
@@ -63,6 +64,11 @@ struct Engine {
 
   // workspace (grow-only)
   DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
+  // strict precision mode (PG_PREC_FP32): lo halves of the split-bf16 operands, fp32 GEMM outputs, row-attention scores
+  DevBuf h_lo, ctx_lo, ffn_lo, ffn_f32, sel_h_lo, scores, zero_bias;
+  bool strict() const { return precision == PG_PREC_FP32; }
+  // out[Mp][N] fp32 (=|+=) X.W^T + b with X = xh + xl, W = w + w_lo:  xh.w + xh.w_lo + xl.w  (three MFMA GEMMs)
+  int dense3(const bf16_t* xh, const bf16_t* xl, const DenseW& W, float* out, int Mp, bool accumulate);
   Prof prof;
 
   ~Engine();

@@ -6,6 +6,10 @@
 
 namespace pg {
 
+// a "sequence" for the attention kernels: sequence s covers token rows
+//   (s / inner_count) * outer_rows + (s % inner_count) * inner_rows + t * row_step,  t = 0..T-1
+struct SeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
+
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_GELU = 4 };
 
 // out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M, N multiples of 128, K of 64 (buffers are row-padded).
@@ -18,9 +22,6 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
 // fused attention, one (sequence, head) per workgroup; qkv rows are [q | k | v] with head h at h*64
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
                           int k_off, int v_off);
-// same kernel over strided sequences: sequence s covers token rows
-//   (s / inner_count) * outer_rows + (s % inner_count) * inner_rows + t * row_step,  t = 0..T-1
-struct SeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
 int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int64_t n_seq, int T, int H, int ld_qkv,
                               int ld_ctx, int k_off, int v_off, SeqLayout sl);
 // MSA tied row attention: one C x C map per (msa, head) from scores summed over the R rows
@@ -31,11 +32,21 @@ int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, co
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,
                     int mask_idx, int token_dropout, int rows_per_msa, float eps);
 int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
-                          int d, float eps);
+                          int d, float eps, bf16_t* h_lo = nullptr);
 int launch_layernorm_f32(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t M, int d,
                          float eps);
 int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, const int32_t* row_map, int P, int width,
-                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps);
+                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps,
+                          bf16_t* h_lo = nullptr);
+// strict precision mode: fp32 -> (hi, lo) bf16 pair (optionally through erf-GELU); fp32 GELU in place
+int launch_split_bf16(hipStream_t s, const float* src, bf16_t* hi, bf16_t* lo, int64_t n, float scale, bool gelu);
+int launch_gelu_f32(hipStream_t s, float* p, int64_t n);
+// strict precision mode attention: fp32 qkv in, softmax and accumulation in fp32 (VALU), ctx out as a (hi, lo) pair
+int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx_hi, bf16_t* ctx_lo, int64_t n_seq, int T, int H,
+                         int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl);
+// strict tied row attention; `scores` is an fp32 scratch of B*H*C*C floats
+int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx_hi, bf16_t* ctx_lo, int B, int R,
+                                 int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale);
 int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const float* beta, const float* embed,
                    const float* out_bias, float* logits, int64_t n, int d, int V, float eps);
 int launch_f32_to_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t n, float scale);

@@ -20,12 +20,32 @@ pytestmark = pytest.mark.gpu
 BF16_TOL = 0.15
 
 
-def _model(cfg_kw, sd):
+STRICT_TOL = 1e-3    # north_star: "within 1e-3 on emitted logits" -- met by the strict precision mode (PG_PREC_FP32)
+
+
+def _model(cfg_kw, sd, precision="bf16"):
     cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=cfg_kw["d_model"], n_layers=cfg_kw["n_layers"],
                               d_ffn=cfg_kw["d_ffn"], max_positions=cfg_kw["max_pos"])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return models.ESM1b(state_dict=sd, config=cfg)
+        return models.ESM1b(state_dict=sd, config=cfg, precision=precision)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_strict_mode_logits_within_1e3(name):
+    z = np.load("%s/esm_hf_%s.npz" % (GOLDEN, name))
+    ck = json.loads(str(z["cfg"]))
+    ocfg = EsmConfig(**ck)
+    sd = synthetic_esm_weights(ocfg, seed=int(z["seed"]), std=float(z["std"]), embed_std=float(z["embed_std"]),
+                               ln_jitter=float(z["ln_jitter"]))
+    m = _model(ck, sd, "fp32")
+    m.model.to("cuda:0")
+    got = m.model.forward_logits(z["tokens"])
+    want = esm1b_forward(sd, ocfg, z["tokens"])
+    e_or, e_hf = np.abs(got - want).max(), np.abs(got - z["logits"]).max()
+    print("\n[strict %s] max|engine - oracle| = %.3e, max|engine - HF| = %.3e (logit std %.2f)" % (name, e_or, e_hf, want.std()))
+    assert e_or < STRICT_TOL and e_hf < STRICT_TOL
+    assert (got.argmax(-1) == want.argmax(-1)).mean() > 0.999
 
 
 @pytest.mark.parametrize("name", ["tiny", "small"])

@@ -53,12 +53,29 @@ def test_column_attention_kernel(B, R, C, H):
 CK = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=80, max_rows=16)
 
 
-def _model(sd, ck=CK):
+def _model(sd, ck=CK, precision="bf16"):
     cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=ck["d_model"], n_layers=ck["n_layers"], d_ffn=ck["d_ffn"],
                               max_positions=ck["max_pos"], max_msa_rows=ck["max_rows"])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return models.ESM_MSA1(state_dict=sd, config=cfg)
+        return models.ESM_MSA1(state_dict=sd, config=cfg, precision=precision)
+
+
+def test_msa_strict_mode_logits_within_1e3():
+    ocfg = MsaConfig(**CK)
+    sd = synthetic_msa_weights(ocfg, seed=4, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    m = _model(sd, precision="fp32").model.to("cuda:0")
+    rng = np.random.default_rng(1)
+    for (B, R, C) in [(2, 4, 21), (1, 7, 66), (3, 1, 10), (1, 3, 130)]:
+        tok = rng.integers(4, 24, (B, R, C))
+        tok[rng.random((B, R, C)) < 0.1] = 30
+        tok[rng.random((B, R, C)) < 0.1] = 32
+        tok[..., 0] = 0
+        got = m.forward_logits(tok)
+        want = msa_forward(sd, ocfg, tok)
+        err = np.abs(got - want).max()
+        print("\nMSA strict forward %s: max|engine - oracle| = %.3e (logit std %.2f)" % ((B, R, C), err, want.std()))
+        assert err < 1e-3
 
 
 def test_msa_forward_logits_vs_oracle():
