@@ -153,6 +153,89 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Coalesced epilogue of the 256x256 kernels.  A lane's MFMA result is 4 consecutive output features of ONE token
+// row, so direct stores are 32 scattered 8/16-byte pieces per lane: measured store-issue-bound (0.19 ms of a 0.79 ms
+// QKV GEMM).  Instead the tile goes through the (now idle) 128 KB of LDS -- XOR-swizzled so both the fragment-shaped
+// writes and the row-shaped reads are conflict-free -- and leaves as full rows: every wave-instruction stores
+// 64 lanes x 16 B = 1 KiB of contiguous output (bf16: two 512-B rows; fp32: one 1-KB row; the fp32 residual
+// read-modify-write uses the same row-shaped accesses, 16 loads in flight per lane).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int wm, int wn, int wave, int lane, int m0,
+                                             int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo) {
+  const int fr = lane & 15, fq = lane >> 4;
+  __syncthreads();
+  if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 b4 = *(const float4*)(bias + n0 + wn * 64 + i * 16 + fq * 4);
+      const int c = wn * 8 + i * 2 + (fq >> 1);                   // 16-B chunk of the 512-B row
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = wm * 128 + j * 16 + fr;
+        float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+        if (EPI == EPI_BF16_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+        uint2 p;
+        p.x = pack_bf16x2(v0, v1);
+        p.y = pack_bf16x2(v2, v3);
+        *(uint2*)(smem + row * 512 + ((c ^ (row & 31)) << 4) + (fq & 1) * 8) = p;
+      }
+    }
+    __syncthreads();
+    const int c = lane & 31;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = (wave * 16 + it) * 2 + (lane >> 5);
+      const uint4 v = *(const uint4*)(smem + row * 512 + ((c ^ (row & 31)) << 4));
+      *(uint4*)((bf16_t*)out + (size_t)(m0 + row) * ldo + n0 + c * 8) = v;
+    }
+  } else {
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      if (ph) __syncthreads();
+      if (wm == ph) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 b4 = *(const float4*)(bias + n0 + wn * 64 + i * 16 + fq * 4);
+          const int c = wn * 16 + i * 4 + fq;                     // 16-B chunk of the 1-KB row
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int row = j * 16 + fr;
+            float4 v = make_float4(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w);
+            if (EPI == EPI_F32_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            *(float4*)(smem + row * 1024 + ((c ^ (row & 63)) << 4)) = v;
+          }
+        }
+      }
+      __syncthreads();
+      float* obase = (float*)out + (size_t)(m0 + ph * 128 + wave * 16) * ldo + n0 + lane * 4;
+      if (EPI == EPI_F32_RESID) {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {          // two batches of 8 rows: 8 loads in flight per lane, no spills
+          float4 r[8];
+#pragma unroll
+          for (int it = 0; it < 8; ++it) r[it] = *(const float4*)(obase + (size_t)(hb * 8 + it) * ldo);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int row = wave * 16 + hb * 8 + it;
+            const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 63)) << 4));
+            r[it].x += v.x; r[it].y += v.y; r[it].z += v.z; r[it].w += v.w;
+            *(float4*)(obase + (size_t)(hb * 8 + it) * ldo) = r[it];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int row = wave * 16 + it;
+          *(float4*)(obase + (size_t)it * ldo) = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 63)) << 4));
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // "Ping-pong" 256x256x64 kernel (the hot one).
 //
@@ -247,25 +330,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       // ---------------- L segment: fragments of (t, kk) + DMA of (t+1, kk) ----------------
-      const char* hb = smem + (((ABL == 1 ? 0 : (t & 1)) * 2) + kk) * HALF_BYTES;
-      if (has_next && ABL != 1) stage_half(t + 1, kk);
-      if (ABL != 3 || t == 0) {
+      constexpr bool NO_DMA = (ABL == 1 || ABL == 8 || ABL == 9 || ABL == 11), NO_DS = (ABL == 3 || ABL == 8 || ABL == 9 || ABL == 11 || ABL == 12),
+                     NO_BAR = (ABL == 9 || ABL == 11 || ABL == 12);
+      const char* hb = smem + (((NO_DMA ? 0 : (t & 1)) * 2) + kk) * HALF_BYTES;
+      if (has_next && !NO_DMA) stage_half(t + 1, kk);
+      if (!NO_DS || t == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(hb + woff + i * 1024);
 #pragma unroll
         for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(hb + xoff + j * 1024);
       }
-      if (has_next && ABL != 1) {
+      if (has_next && !NO_DMA) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the 4 pieces just issued
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (!NO_BAR) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- C segment: 32 MFMAs ----------------
       __builtin_amdgcn_s_setprio(1);
-      if (ABL != 2) {
+      if (ABL != 2 && ABL != 12) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -279,64 +364,159 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (!NO_BAR) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
 
-  // epilogue: lane holds D[n = nb + fq*4 + r][m = mb + fr]
-  if (EPI == EPI_F32_RESID) {
-    // fp32 residual stream read-modify-write.  x streams from HBM (it never fits a cache), so the loads are issued
-    // in two batches of 16 x 16 B per lane before any is consumed: 2 memory round trips instead of one per tile row.
+  if (ABL == 10 || ABL == 11 || ABL == 12) {     // ablation: keep the accumulators alive, store nothing
 #pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      float4 r[2][8];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int n = n0 + wn * 64 + (ih * 2 + i2) * 16 + fq * 4;
-          const int m = m0 + wm * 128 + j * 16 + fr;
-          r[i2][j] = *(const float4*)((const float*)out + (size_t)m * ldo + n);
-        }
-#pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
-        const int i = ih * 2 + i2;
-        const int n = n0 + wn * 64 + i * 16 + fq * 4;
-        const float4 b4 = *(const float4*)(bias + n);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int m = m0 + wm * 128 + j * 16 + fr;
-          float4 v = r[i2][j];
-          v.x += acc[i][j][0] + b4.x; v.y += acc[i][j][1] + b4.y; v.z += acc[i][j][2] + b4.z; v.w += acc[i][j][3] + b4.w;
-          *(float4*)((float*)out + (size_t)m * ldo + n) = v;
-        }
-      }
-    }
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wn * 64 + i * 16 + fq * 4;
-    const float4 b4 = *(const float4*)(bias + n);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = m0 + wm * 128 + j * 16 + fr;
-      float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-      if (EPI == EPI_BF16_GELU || EPI == EPI_F32_GELU) {
-        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
-      }
-      if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
-        uint2 p;
-        p.x = pack_bf16x2(v0, v1);
-        p.y = pack_bf16x2(v2, v3);
-        *(uint2*)((bf16_t*)out + (size_t)m * ldo + n) = p;
-      } else {
-        *(float4*)((float*)out + (size_t)m * ldo + n) = make_float4(v0, v1, v2, v3);
-      }
-    }
+  epilogue_256<EPI>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "v3": fine-grained software pipeline.  PMC on the kernels above showed waves 55 % in issue stalls: LDS-DMA
+// pieces issued in bursts fill the CU's VMEM queue (~160 cycles per piece), and a wave stuck issuing DMA cannot
+// issue MFMAs.  Here every wave runs the same stream, and per K half-step (32 MFMAs) it interleaves, after each
+// group of 4 MFMAs: the ds_read_b128 that PREFETCH the next half-step's fragments (X fragments reuse the
+// register the group just consumed; W fragments are double-buffered) and, every other group, ONE DMA piece of the
+// half-step four ahead -- so the DMA queue sees one piece per ~8 MFMAs per wave instead of bursts, and the two
+// waves of a SIMD cover each other's issue slots.
+//   LDS: ring of 4 half-step slots (32 KB each, same swizzled 64-B-row layout as the ping-pong kernel).
+//   boundary(h) = { lgkmcnt(0); vmcnt(8) [slot h+1 landed; h+2, h+3 still in flight]; s_barrier }, one per half-step.
+//   slot h%4 is re-filled (half-step h+4) during compute(h): its fragments were read during compute(h-1) and
+//   boundary(h) proves every wave's reads completed.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int GM = 4>
+__global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                          const float* __restrict__ bias, void* __restrict__ out, int K,
+                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+  constexpr int HALF_BYTES = 512 * 64;
+  __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = n_tiles >> 3, r = n_tiles & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  int tile_m, tile_n;
+  {
+    const int tiles_m = n_tiles / tiles_n;
+    const int gsz = GM * tiles_n, g = bid / gsz, within = bid - g * gsz;
+    const int rows = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
+    tile_m = g * GM + within % rows;
+    tile_n = within / rows;
+  }
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  // DMA addressing: wave stages pieces (wave&3)*4 + i of the X half-tile (waves 0-3) or W half-tile (waves 4-7);
+  // address = wave-uniform base (SGPR) + per-lane 32-bit byte offset (VGPR)
+  const bool stage_w = wave >= 4;
+  const int lds_ = stage_w ? ldw : ldx;
+  const char* ubase = (const char*)((stage_w ? W : X) + (size_t)((stage_w ? n0 : m0) + (wave & 3) * 64) * lds_);
+  const unsigned loff = (unsigned)(((lane >> 2) * lds_ + (((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8)) * 2);
+  const size_t piece_bytes = (size_t)16 * lds_ * 2;
+  const int lds_piece0 = (stage_w ? 256 * 64 : 0) + (wave & 3) * 4 * 1024;
+
+  auto stage_piece = [&](int hstep, int i) {
+    char* dst = smem + (hstep & 3) * HALF_BYTES + lds_piece0 + i * 1024;
+    const char* g = ubase + (size_t)hstep * 64 + i * piece_bytes + loff;      // hstep*32 bf16 = hstep*64 bytes
+    __builtin_amdgcn_global_load_lds(PG_GLB_PTR(g), PG_LDS_PTR(dst), 16, 0, 0);
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nh = K / 32;                         // half-steps (K multiple of 64 -> nh even, >= 2)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int foff = fr * 64 + ((fq ^ ((0 - (fr >> 2)) & 3)) << 4);
+  const int xoff = (wm * 128) * 64 + foff;
+  const int woff = 256 * 64 + (wn * 64) * 64 + foff;
+
+  // ---- prologue: fill the ring, fetch the fragments of half-step 0
+#pragma unroll
+  for (int h = 0; h < 4; ++h)
+    if (h < nh) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stage_piece(h, i);
+    }
+  if (nh >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wfa[4], wfb[4], xf[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wfa[i] = *(const bf16x8*)(smem + woff + i * 1024);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(smem + xoff + j * 1024);
+
+  // one half-step; CUR/NXT select the W-fragment buffers at compile time
+#define PG_V3_HALFSTEP(h, WCUR, WNXT)                                                                          \
+  {                                                                                                            \
+    const int rem = nh - ((h) + 2);          /* how many of {h+2, h+3} exist */                                \
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                  \
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                             \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    const bool more = (h) + 1 < nh;                                                                            \
+    const bool dma = (h) + 4 < nh;                                                                             \
+    const char* nslot = smem + (((h) + 1) & 3) * HALF_BYTES;                                                   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WCUR[i], xf[j], acc[i][j], 0, 0, 0);             \
+      if (more) {                                                                                              \
+        xf[j] = *(const bf16x8*)(nslot + xoff + j * 1024);                                                     \
+        if (j < 4) WNXT[j] = *(const bf16x8*)(nslot + woff + j * 1024);                                        \
+      }                                                                                                        \
+      if (dma && (j & 1) == 0) stage_piece((h) + 4, j >> 1);                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  }
+
+  for (int h = 0; h < nh; h += 2) {
+    PG_V3_HALFSTEP(h, wfa, wfb)
+    PG_V3_HALFSTEP(h + 1, wfb, wfa)
+  }
+#undef PG_V3_HALFSTEP
+
+  epilogue_256<EPI>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
+}
+
+static int launch_v3(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
+                     int ldx, int ldw, int ldo, int epi) {
+  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+  dim3 grid(n_tiles), block(512);
+#define PG_GEMM_CASE(E)                                                                                        \
+  case E:                                                                                                      \
+    hipLaunchKernelGGL((gemm_bf16_v3_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, \
+                       n_tiles);                                                                               \
+    break;
+  switch (epi) {
+    PG_GEMM_CASE(EPI_BF16)
+    PG_GEMM_CASE(EPI_BF16_GELU)
+    PG_GEMM_CASE(EPI_F32_RESID)
+    PG_GEMM_CASE(EPI_F32)
+    PG_GEMM_CASE(EPI_F32_GELU)
+    default:
+      return fail(1, "gemm: bad epilogue");
+  }
+#undef PG_GEMM_CASE
+  PG_HIP(hipGetLastError());
+  return 0;
 }
 
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
@@ -347,6 +527,11 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
     if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
     if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
     if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
     if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
     if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
@@ -406,6 +591,7 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant) {
   if (M % 128 || N % 128 || K % 64) return fail(1, "gemm: M,N must be multiples of 128 and K of 64");
+  if (M % 256 == 0 && N % 256 == 0 && variant == 3) return launch_v3(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (M % 256 == 0 && N % 256 == 0 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
   if (M % 256 == 0 && N % 256 == 0 && variant >= 2) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (M % 256 == 0 && N % 256 == 0) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
