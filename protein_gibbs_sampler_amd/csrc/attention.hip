@@ -41,51 +41,104 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
   // All MAXKB key blocks are computed unconditionally: K rows / V^T columns past T are zero-filled and
   // their scores are masked, so no wave-uniform branches (and no dynamic register indexing) are needed.
-  constexpr int nkb = MAXKB;
   constexpr int nkc = MAXKB / 2;
   constexpr int tpad = MAXKB * 16;
 
-  // ---- stage K (swizzled rows) ------------------------------------------------------------
-  for (int i = tid; i < nkb * 16 * 8; i += 256) {
-    const int row = i >> 3, c = i & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < T) v = *(const uint4*)(base + (size_t)row * ld_qkv + k_off + c * 8);
-    *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = v;
-  }
-  // ---- stage V^T: lane <-> key, so transposed 2-byte LDS writes are bank-conflict free -------
-  for (int i = tid; i < tpad * 8; i += 256) {
-    const int key = i % tpad, c = i / tpad;   // tpad is a multiple of 32; a wave covers 64 keys of one chunk
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (key < T) v = *(const uint4*)(base + (size_t)key * ld_qkv + v_off + c * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  // ---- stage K (swizzled rows) and V^T.  All global loads are issued before the first LDS write so a block pays
+  //      ~one memory round trip, not one per loop iteration (the loops have MAXKB/2 compile-time trips).
+  {
+    constexpr int NIT = (MAXKB * 16 * 8 + 255) / 256;       // K: one uint4 (8 d of one key) per item
+    constexpr int NVP = (MAXKB * 8 * 8 + 255) / 256;        // V: one item = 2 adjacent keys x 8 d
+    constexpr int hpad = tpad / 2;
+    uint4 kreg[NIT], va[NVP], vb[NVP];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VT_LD + key] = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      const int row = i >> 3, c = i & 7;
+      kreg[it] = make_uint4(0, 0, 0, 0);
+      if (i < tpad * 8 && row < T) kreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + k_off + c * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NVP; ++it) {
+      const int i = tid + it * 256;
+      const int kp = i % hpad, cv = i / hpad;   // lane <-> key pair: packed 4-byte transposed LDS writes, conflict-free
+      va[it] = make_uint4(0, 0, 0, 0);
+      vb[it] = make_uint4(0, 0, 0, 0);
+      if (i < hpad * 8) {
+        if (2 * kp < T) va[it] = *(const uint4*)(base + (size_t)(2 * kp) * ld_qkv + v_off + cv * 8);
+        if (2 * kp + 1 < T) vb[it] = *(const uint4*)(base + (size_t)(2 * kp + 1) * ld_qkv + v_off + cv * 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      if (i < tpad * 8) {
+        const int row = i >> 3, c = i & 7;
+        *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NVP; ++it) {
+      const int i = tid + it * 256;
+      if (i < hpad * 8) {
+        const int kp = i % hpad, cv = i / hpad;
+        const uint32_t a[4] = {va[it].x, va[it].y, va[it].z, va[it].w}, b[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
+        uint32_t* vt32 = (uint32_t*)Vt;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (b[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+          vt32[((cv * 8 + e) * VT_LD) / 2 + kp] = lo | (hi << 16);
+        }
+      }
+    }
   }
   __syncthreads();
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nqb = (T + 15) >> 4;  // query blocks of 16
-  for (int qb = wave; qb < nqb; qb += 4) {
-    // Q fragment (MFMA B operand): query fr, d = kk*32 + fq*8 .. +7
+  // Q fragment (MFMA B operand): query fr, d = kk*32 + fq*8 .. +7; the next block's fragment is prefetched while
+  // the current one is computed (a wave has nothing else to cover a global round trip with)
+  bf16x8 qf[2], qn[2];
+  auto load_q = [&](int qb, bf16x8 (&dst)[2]) {
     int qrow = qb * 16 + fr;
     if (qrow >= T) qrow = T - 1;
-    bf16x8 qf[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
+    for (int kk = 0; kk < 2; ++kk) dst[kk] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
+  };
+  if (wave < nqb) load_q(wave, qf);
+  for (int qb = wave; qb < nqb; qb += 4) {
+    if (qb + 4 < nqb) load_q(qb + 4, qn);
 
     // S^T blocks: st[kb][r] = S[query fr][key kb*16 + fq*4 + r]
     f32x4 st[MAXKB];
+    {
+      // K fragments are fetched one chunk (CH key blocks) ahead of the MFMAs that use them: with 2 waves per SIMD
+      // the LDS latency must be covered inside the wave (PMC: 44 % of wave cycles were s_waitcnt before this)
+      constexpr int CH = (MAXKB % 6 == 0) ? 6 : (MAXKB % 4 == 0 ? 4 : 2);
+      bf16x8 kbuf[2][CH][2];
+      auto load_chunk = [&](int ch, bf16x8 (&dst)[CH][2]) {
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb) {
-      st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int krow = kb * 16 + fr;
+        for (int u = 0; u < CH; ++u) {
+          const int krow = (ch * CH + u) * 16 + fr;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+          for (int kk = 0; kk < 2; ++kk) dst[u][kk] = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
+        }
+      };
+      load_chunk(0, kbuf[0]);
+#pragma unroll
+      for (int ch = 0; ch < MAXKB / CH; ++ch) {
+        if (ch + 1 < MAXKB / CH) load_chunk(ch + 1, kbuf[(ch + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][0], qf[0], a, 0, 0, 0);
+          st[ch * CH + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][1], qf[1], a, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // exact softmax over keys (lane-local + 4-lane reduction)
+    // exact softmax over keys (lane-local + 4-lane reduction); exp(s - m) = exp2(s*log2e - m*log2e)
     float mx = -3.0e38f;
     int tl = T - fq * 4;                      // key kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
     asm volatile("" : "+v"(tl));              // keep the compares inside the loop (no hoisted lane masks)
@@ -99,39 +152,52 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mneg = -mx * 1.44269504088896341f;
     float sum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < MAXKB; ++kb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(st[kb][r] - mx);
+        const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r], 1.44269504088896341f, mneg));
         st[kb][r] = e;
         sum += e;
       }
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    const float inv = 1.0f / sum;             // applied to O at the end: the lane's query (fr) is also its O column
 
     // O^T[d][q] = sum_key V^T[d][key] * P^T[key][q]; K-slot (fq*8 + j) of chunk c <-> key (2c + (j>>2))*16 + fq*4 + (j&3)
     f32x4 o[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      // V^T fragments fetched two 32-key chunks ahead of the PV MFMAs
+      union VF { bf16x8 v; uint2 h[2]; };
+      VF vbuf[3][4];
+      auto load_v = [&](int c, VF (&dst)[4]) {
 #pragma unroll
-    for (int c = 0; c < nkc; ++c) {
-      union { bf16x8 v; uint32_t u[4]; } pf;
-      const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
-      pf.u[0] = pack_bf16x2(lo[0] * inv, lo[1] * inv);
-      pf.u[1] = pack_bf16x2(lo[2] * inv, lo[3] * inv);
-      pf.u[2] = pack_bf16x2(hi[0] * inv, hi[1] * inv);
-      pf.u[3] = pack_bf16x2(hi[2] * inv, hi[3] * inv);
+        for (int db = 0; db < 4; ++db) {
+          const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
+          dst[db].h[0] = *(const uint2*)(vrow);
+          dst[db].h[1] = *(const uint2*)(vrow + 16);
+        }
+      };
+      load_v(0, vbuf[0]);
+      if (nkc > 1) load_v(1, vbuf[1]);
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        union { bf16x8 v; uint2 h[2]; } vf;
-        const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
-        vf.h[0] = *(const uint2*)(vrow);
-        vf.h[1] = *(const uint2*)(vrow + 16);
-        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+      for (int c = 0; c < nkc; ++c) {
+        if (c + 2 < nkc) load_v(c + 2, vbuf[(c + 2) % 3]);
+        union { bf16x8 v; uint32_t u[4]; } pf;
+        const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
+        pf.u[0] = pack_bf16x2(lo[0], lo[1]);
+        pf.u[1] = pack_bf16x2(lo[2], lo[3]);
+        pf.u[2] = pack_bf16x2(hi[0], hi[1]);
+        pf.u[3] = pack_bf16x2(hi[2], hi[3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vbuf[c % 3][db].v, pf.v, o[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // store: lane holds O[q = qb*16 + fr][d = db*16 + fq*4 + r]
@@ -141,11 +207,13 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 p;
-        p.x = pack_bf16x2(o[db][0], o[db][1]);
-        p.y = pack_bf16x2(o[db][2], o[db][3]);
+        p.x = pack_bf16x2(o[db][0] * inv, o[db][1] * inv);
+        p.y = pack_bf16x2(o[db][2] * inv, o[db][3] * inv);
         *(uint2*)(dst + db * 16) = p;
       }
     }
+    qf[0] = qn[0];
+    qf[1] = qn[1];
   }
 }
 
