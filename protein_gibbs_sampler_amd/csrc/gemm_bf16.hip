@@ -380,144 +380,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   epilogue_256<EPI>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
 }
 
-// ------------------------------------------------------------------------------------------------
-// "v3": fine-grained software pipeline.  PMC on the kernels above showed waves 55 % in issue stalls: LDS-DMA
-// pieces issued in bursts fill the CU's VMEM queue (~160 cycles per piece), and a wave stuck issuing DMA cannot
-// issue MFMAs.  Here every wave runs the same stream, and per K half-step (32 MFMAs) it interleaves, after each
-// group of 4 MFMAs: the ds_read_b128 that PREFETCH the next half-step's fragments (X fragments reuse the
-// register the group just consumed; W fragments are double-buffered) and, every other group, ONE DMA piece of the
-// half-step four ahead -- so the DMA queue sees one piece per ~8 MFMAs per wave instead of bursts, and the two
-// waves of a SIMD cover each other's issue slots.
-//   LDS: ring of 4 half-step slots (32 KB each, same swizzled 64-B-row layout as the ping-pong kernel).
-//   boundary(h) = { lgkmcnt(0); vmcnt(8) [slot h+1 landed; h+2, h+3 still in flight]; s_barrier }, one per half-step.
-//   slot h%4 is re-filled (half-step h+4) during compute(h): its fragments were read during compute(h-1) and
-//   boundary(h) proves every wave's reads completed.
-// ------------------------------------------------------------------------------------------------
-template <int EPI, int GM = 4>
-__global__ __launch_bounds__(512) void gemm_bf16_v3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                          const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
-  constexpr int HALF_BYTES = 512 * 64;
-  __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = n_tiles >> 3, r = n_tiles & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int tile_m, tile_n;
-  {
-    const int tiles_m = n_tiles / tiles_n;
-    const int gsz = GM * tiles_n, g = bid / gsz, within = bid - g * gsz;
-    const int rows = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
-    tile_m = g * GM + within % rows;
-    tile_n = within / rows;
-  }
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
-
-  // DMA addressing: wave stages pieces (wave&3)*4 + i of the X half-tile (waves 0-3) or W half-tile (waves 4-7);
-  // address = wave-uniform base (SGPR) + per-lane 32-bit byte offset (VGPR)
-  const bool stage_w = wave >= 4;
-  const int lds_ = stage_w ? ldw : ldx;
-  const char* ubase = (const char*)((stage_w ? W : X) + (size_t)((stage_w ? n0 : m0) + (wave & 3) * 64) * lds_);
-  const unsigned loff = (unsigned)(((lane >> 2) * lds_ + (((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 8)) * 2);
-  const size_t piece_bytes = (size_t)16 * lds_ * 2;
-  const int lds_piece0 = (stage_w ? 256 * 64 : 0) + (wave & 3) * 4 * 1024;
-
-  auto stage_piece = [&](int hstep, int i) {
-    char* dst = smem + (hstep & 3) * HALF_BYTES + lds_piece0 + i * 1024;
-    const char* g = ubase + (size_t)hstep * 64 + i * piece_bytes + loff;      // hstep*32 bf16 = hstep*64 bytes
-    __builtin_amdgcn_global_load_lds(PG_GLB_PTR(g), PG_LDS_PTR(dst), 16, 0, 0);
-  };
-
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nh = K / 32;                         // half-steps (K multiple of 64 -> nh even, >= 2)
-  const int fr = lane & 15, fq = lane >> 4;
-  const int foff = fr * 64 + ((fq ^ ((0 - (fr >> 2)) & 3)) << 4);
-  const int xoff = (wm * 128) * 64 + foff;
-  const int woff = 256 * 64 + (wn * 64) * 64 + foff;
-
-  // ---- prologue: fill the ring, fetch the fragments of half-step 0
-#pragma unroll
-  for (int h = 0; h < 4; ++h)
-    if (h < nh) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) stage_piece(h, i);
-    }
-  if (nh >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  bf16x8 wfa[4], wfb[4], xf[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) wfa[i] = *(const bf16x8*)(smem + woff + i * 1024);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(smem + xoff + j * 1024);
-
-  // one half-step; CUR/NXT select the W-fragment buffers at compile time
-#define PG_V3_HALFSTEP(h, WCUR, WNXT)                                                                          \
-  {                                                                                                            \
-    const int rem = nh - ((h) + 2);          /* how many of {h+2, h+3} exist */                                \
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                  \
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                             \
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    const bool more = (h) + 1 < nh;                                                                            \
-    const bool dma = (h) + 4 < nh;                                                                             \
-    const char* nslot = smem + (((h) + 1) & 3) * HALF_BYTES;                                                   \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WCUR[i], xf[j], acc[i][j], 0, 0, 0);             \
-      if (more) {                                                                                              \
-        xf[j] = *(const bf16x8*)(nslot + xoff + j * 1024);                                                     \
-        if (j < 4) WNXT[j] = *(const bf16x8*)(nslot + woff + j * 1024);                                        \
-      }                                                                                                        \
-      if (dma && (j & 1) == 0) stage_piece((h) + 4, j >> 1);                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-    }                                                                                                          \
-  }
-
-  for (int h = 0; h < nh; h += 2) {
-    PG_V3_HALFSTEP(h, wfa, wfb)
-    PG_V3_HALFSTEP(h + 1, wfb, wfa)
-  }
-#undef PG_V3_HALFSTEP
-
-  epilogue_256<EPI>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
-}
-
-static int launch_v3(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi) {
-  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
-  dim3 grid(n_tiles), block(512);
-#define PG_GEMM_CASE(E)                                                                                        \
-  case E:                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_v3_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, \
-                       n_tiles);                                                                               \
-    break;
-  switch (epi) {
-    PG_GEMM_CASE(EPI_BF16)
-    PG_GEMM_CASE(EPI_BF16_GELU)
-    PG_GEMM_CASE(EPI_F32_RESID)
-    PG_GEMM_CASE(EPI_F32)
-    PG_GEMM_CASE(EPI_F32_GELU)
-    default:
-      return fail(1, "gemm: bad epilogue");
-  }
-#undef PG_GEMM_CASE
-  PG_HIP(hipGetLastError());
-  return 0;
-}
+// Measured alternatives that were NOT faster on MI355X and were removed again (numbers: QKV GEMM, M=66048 N=3840 K=1280):
+//   * "v3" -- all waves in lockstep, DMA pieces and fragment prefetch interleaved after every 4 MFMAs, 4-slot ring,
+//     one barrier per half-step: 855 TF vs 920 TF for the ping-pong kernel;
+//   * ping-pong on v_mfma_f32_32x32x16_bf16: 761 TF (identical SQ_VALU_MFMA_BUSY_CYCLES, more issue stalls);
+//   * peeling the partial last round of tiles into a 128x128 launch: no gain (blocks do not run in lockstep rounds).
+// Ablations of the ping-pong kernel (tools/gemm_bench.py variants 21-32): MFMA-only 0.43 ms, DMA-only 0.32 ms,
+// full loop without epilogue 0.60 ms, with the coalesced epilogue 0.71 ms (was 0.79 ms with per-lane stores).
 
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, int abl = 0) {
@@ -591,7 +460,6 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant) {
   if (M % 128 || N % 128 || K % 64) return fail(1, "gemm: M,N must be multiples of 128 and K of 64");
-  if (M % 256 == 0 && N % 256 == 0 && variant == 3) return launch_v3(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (M % 256 == 0 && N % 256 == 0 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
   // (Peeling the 1-3 % full last round of tiles into a trailing 128x128 launch was measured: no gain -- blocks do not
   //  run in lockstep rounds, the dispatcher back-fills -- so every 256-multiple shape goes to one launch.)
