@@ -81,7 +81,7 @@ int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, flo
   Engine& e = h->e;
   if (e.cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
   if (B < 0 || T < 1) return fail(PG_ERR_INVALID, "bad shape");
-  if (T > e.cfg.max_positions + 2) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
+  if (T > e.cfg.max_positions) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
   if (B == 0) return PG_OK;
   DeviceGuard g(e.device);
   const int64_t M = (int64_t)B * T;

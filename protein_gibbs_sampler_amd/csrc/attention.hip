@@ -5,7 +5,8 @@
 //
 // CDNA4 mapping (head dim is 64 in ESM-1b and MSA-1b):
 //   * grid = B*H workgroups of 4 waves; K (row-major, XOR-swizzled 16-B chunks) and V^T live in LDS for
-//     the whole sequence (T <= 576: 72 KB + 74 KB) and are shared by all query blocks.
+//     the whole sequence (T <= 576: 72 KB + 74 KB) and are shared by all query blocks; longer sequences use
+//     attention_long_kernel (288-key tiles, online softmax).
 //   * per wave, 16 queries at a time: S^T = K.Q^T with v_mfma_f32_16x16x32_bf16 ("swapped" product), so a
 //     lane holds, for ONE query (lane & 15), 4 consecutive keys of every 16-key block: the whole score
 //     row is lane-local except for a 4-lane (xor 16, 32) shuffle reduction -> exact (non-online) softmax
@@ -217,6 +218,155 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long sequences (T > 576, up to the 1024-token limit of the learned position table): same MFMA formulation, keys
+// processed in tiles of 288 with the online-softmax recurrence (running max m, running sum l, rescaled O).
+// One workgroup = (sequence, head, 64 queries); wave w owns one 16-query block for the whole key loop, so the
+// per-wave state is just O (16 regs) + m + l; every workgroup streams all K/V tiles of its head (L2-resident).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
+                                                               int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
+                                                               SeqLayout sl, int n_qchunk) {
+  constexpr int MAXKB = 18, tpad = MAXKB * 16, nkc = MAXKB / 2, VT_LD = tpad + 8;
+  __shared__ __attribute__((aligned(16))) char smem[tpad * 128 + 64 * VT_LD * 2];
+  char* Ks = smem;
+  bf16_t* Vt = (bf16_t*)(smem + tpad * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qc = blockIdx.x % n_qchunk, sh = blockIdx.x / n_qchunk;
+  const int seq = sh / H, h = sh % H;
+  const size_t row0 = (size_t)(seq / sl.inner_count) * sl.outer_rows + (size_t)(seq % sl.inner_count) * sl.inner_rows;
+  const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
+  const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int q0 = qc * 64 + wave * 16;
+  const bool active = q0 < T;                        // wave-uniform
+  bf16x8 qf[2];
+  {
+    int qrow = q0 + fr;
+    if (qrow >= T) qrow = T - 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, l = 0.f;
+  constexpr float LOG2E = 1.44269504088896341f;
+
+  for (int k0 = 0; k0 < T; k0 += tpad) {
+    __syncthreads();
+    {   // stage this key tile: K rows swizzled, V^T packed two keys per 32-bit word (as in attention_kernel)
+      constexpr int NIT = (tpad * 8 + 255) / 256, NVP = (tpad / 2 * 8 + 255) / 256, hpad = tpad / 2;
+      uint4 kreg[NIT], va[NVP], vb[NVP];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256, row = i >> 3, c = i & 7;
+        kreg[it] = make_uint4(0, 0, 0, 0);
+        if (i < tpad * 8 && k0 + row < T) kreg[it] = *(const uint4*)(base + (size_t)(k0 + row) * ld_qkv + k_off + c * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < NVP; ++it) {
+        const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
+        va[it] = make_uint4(0, 0, 0, 0);
+        vb[it] = make_uint4(0, 0, 0, 0);
+        if (i < hpad * 8) {
+          if (k0 + 2 * kp < T) va[it] = *(const uint4*)(base + (size_t)(k0 + 2 * kp) * ld_qkv + v_off + cv * 8);
+          if (k0 + 2 * kp + 1 < T) vb[it] = *(const uint4*)(base + (size_t)(k0 + 2 * kp + 1) * ld_qkv + v_off + cv * 8);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256, row = i >> 3, c = i & 7;
+        if (i < tpad * 8) *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
+      }
+#pragma unroll
+      for (int it = 0; it < NVP; ++it) {
+        const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
+        if (i < hpad * 8) {
+          const uint32_t a[4] = {va[it].x, va[it].y, va[it].z, va[it].w}, b[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
+          uint32_t* vt32 = (uint32_t*)Vt;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            vt32[((cv * 8 + e) * VT_LD) / 2 + kp] = ((a[e >> 1] >> ((e & 1) * 16)) & 0xffffu) | (((b[e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
+        }
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    f32x4 st[MAXKB];
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+      st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int krow = kb * 16 + fr;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+      }
+    }
+    float tmax = -3.0e38f;
+    const int tl = T - k0 - fq * 4;              // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
+        tmax = fmaxf(tmax, st[kb][r]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float mn = fmaxf(m, tmax);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+    const float mneg = -mn * LOG2E;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r], LOG2E, mneg));
+        st[kb][r] = e;
+        psum += e;
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    m = mn;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+    }
+#pragma unroll
+    for (int c = 0; c < nkc; ++c) {
+      union { bf16x8 v; uint32_t u[4]; } pf;
+      const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
+      pf.u[0] = pack_bf16x2(lo[0], lo[1]);
+      pf.u[1] = pack_bf16x2(lo[2], lo[3]);
+      pf.u[2] = pack_bf16x2(hi[0], hi[1]);
+      pf.u[3] = pack_bf16x2(hi[2], hi[3]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        union { bf16x8 v; uint2 h2[2]; } vf;
+        const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
+        vf.h2[0] = *(const uint2*)(vrow);
+        vf.h2[1] = *(const uint2*)(vrow + 16);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+      }
+    }
+  }
+  const int q = q0 + fr;
+  if (active && q < T) {
+    const float inv = 1.0f / l;
+    bf16_t* dst = ctx + row0 * ld_ctx_ + (size_t)q * ld_ctx + h * 64 + fq * 4;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      uint2 p;
+      p.x = pack_bf16x2(o[db][0] * inv, o[db][1] * inv);
+      p.y = pack_bf16x2(o[db][2] * inv, o[db][3] * inv);
+      *(uint2*)(dst + db * 16) = p;
+    }
+  }
+}
+
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
                           int k_off, int v_off) {
   SeqLayout sl = {1, T, 0, 1};
@@ -236,7 +386,10 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   PG_ATT(2) PG_ATT(4) PG_ATT(8) PG_ATT(12) PG_ATT(18) PG_ATT(24) PG_ATT(30) PG_ATT(36)
 #undef PG_ATT
   else {
-    return fail(5, "attention: sequences longer than 576 tokens are not supported yet");
+    const int n_qchunk = (T + 63) / 64;
+    if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
+    hipLaunchKernelGGL(attention_long_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), block, 0, s, qkv, ctx, T, H, ld_qkv,
+                       ld_ctx, k_off, v_off, sl, n_qchunk);
   }
   PG_HIP(hipGetLastError());
   return 0;

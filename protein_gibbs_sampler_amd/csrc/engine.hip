@@ -340,7 +340,7 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
                              const pg_sample_params* sp, float* d_samp_logits_, int32_t* d_samp_tok_) {
   if (cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
   if (B < 0 || T < 1 || P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "gibbs: negative size");
-  if (T > cfg.max_positions + 2) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
+  if (T > cfg.max_positions) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
   if (B == 0 || n_iters == 0) return PG_OK;
   const int V = cfg.vocab;
   const int64_t n_sel_rows = B;              // one selected token row per chain
@@ -428,7 +428,20 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C) {
     // tied row attention
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_row.g, L.ln_row.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
-    if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale); }))) return rc;
+    if (C <= 576) {
+      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale); }))) return rc;
+    } else {
+      // alignments wider than the MFMA row-attention kernel's register budget: fp32 scores through a scratch buffer
+      if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * C * 4, stream)) ||
+          (rc = ctx_lo.ensure((size_t)Mp * d * 2, stream))) return rc;
+      rc = timed(PC_ATTN, [&] {
+        int r2 = launch_bf16_to_f32(stream, QKV, scratch.as<float>(), (int64_t)M * 3 * d);
+        if (r2) return r2;
+        return launch_msa_row_attention_f32(stream, scratch.as<float>(), scores.as<float>(), CTX, ctx_lo.as<bf16_t>(), B, R, C, H,
+                                            3 * d, d, d, 2 * d, row_scale);
+      });
+      if (rc) return rc;
+    }
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.row_out.w, L.row_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
     // column attention (q pre-scaled by dh^-0.5 in the weights)
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_col.g, L.ln_col.b, Hh, M, d, eps); }))) return rc;
@@ -447,7 +460,7 @@ static int check_msa_shape(const pg_model_config& cfg, int B, int R, int C) {
   if (cfg.arch != PG_ARCH_MSA1B) return fail(PG_ERR_INVALID, "engine was not built for the MSA-1b architecture");
   if (B < 0 || R < 1 || C < 1) return fail(PG_ERR_INVALID, "bad MSA shape");
   if (R > cfg.max_msa_rows) return fail(PG_ERR_INVALID, "MSA has more rows than msa_position_embedding");
-  if (C > cfg.max_positions + 1) return fail(PG_ERR_INVALID, "alignment longer than the learned position table");
+  if (C > cfg.max_positions) return fail(PG_ERR_INVALID, "alignment longer than the learned position table");
   return PG_OK;
 }
 

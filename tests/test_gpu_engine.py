@@ -99,6 +99,22 @@ def test_gibbs_run_draws_replay_exactly():
         assert (tok == run["tokens"]).all()                        # write-back
 
 
+def test_long_sequence_forward():
+    """T > 576 tokens (ESM-1b allows 1024): online-softmax attention kernel."""
+    ck = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=1024)
+    ocfg = EsmConfig(**ck)
+    sd = synthetic_esm_weights(ocfg, seed=12, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    m = _model(ck, sd).model.to("cuda:0")
+    rng = np.random.default_rng(3)
+    for T in (600, 1024):
+        tok = rng.integers(4, 24, (2, T))
+        tok[:, 0], tok[:, -1] = 0, 2
+        tok[0, 5:40] = 32
+        got = m.forward_logits(tok)
+        want = esm1b_forward(sd, ocfg, tok)
+        assert np.abs(got - want).max() < BF16_TOL
+
+
 def test_engine_rejects_bad_weights_and_shapes():
     ck = dict(d_model=128, n_layers=1, n_heads=2, d_ffn=256, max_pos=40)
     sd = synthetic_esm_weights(EsmConfig(**ck), seed=1)

@@ -51,7 +51,8 @@ def test_layernorm(M, d):
     assert np.abs(y - ref).max() < 2e-5 * max(1, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 27, 2), (3, 258, 2), (1, 16, 1), (2, 100, 3), (1, 200, 1), (1, 300, 2), (1, 513, 1)])
+@pytest.mark.parametrize("B,T,H", [(2, 27, 2), (3, 258, 2), (1, 16, 1), (2, 100, 3), (1, 200, 1), (1, 300, 2), (1, 513, 1),
+                                   (1, 577, 1), (2, 700, 2), (1, 1024, 1)])
 def test_attention(B, T, H):
     rng = np.random.default_rng(T)
     d = H * 64

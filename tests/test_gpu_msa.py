@@ -33,7 +33,7 @@ def test_row_attention_kernel(B, R, C, H):
     assert np.abs(ctx - ref).max() < 2.5e-2 and np.abs(ctx - ref).mean() < 3e-3
 
 
-@pytest.mark.parametrize("B,R,C,H", [(2, 3, 20, 2), (1, 32, 50, 2), (1, 128, 9, 1), (2, 1, 12, 1), (1, 17, 33, 3)])
+@pytest.mark.parametrize("B,R,C,H", [(2, 3, 20, 2), (1, 32, 50, 2), (1, 128, 9, 1), (2, 1, 12, 1), (1, 17, 33, 3), (1, 600, 3, 1)])
 def test_column_attention_kernel(B, R, C, H):
     rng = np.random.default_rng(R)
     d = H * 64
@@ -94,6 +94,20 @@ def test_msa_forward_logits_vs_oracle():
         print("\nMSA forward %s: max|engine - oracle| = %.3e (logit std %.2f), argmax agreement %.4f"
               % ((B, R, C), err, want.std(), (got.argmax(-1) == want.argmax(-1)).mean()))
         assert err < BF16_TOL
+
+
+def test_msa_forward_wide_alignment():
+    """C > 576 columns: row attention takes the fp32-scores path."""
+    ck = dict(d_model=128, n_layers=1, n_heads=2, d_ffn=256, max_pos=700, max_rows=4)
+    ocfg = MsaConfig(**ck)
+    sd = synthetic_msa_weights(ocfg, seed=9, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    m = _model(sd, ck).model.to("cuda:0")
+    rng = np.random.default_rng(2)
+    tok = rng.integers(4, 24, (1, 2, 640))
+    tok[..., 0] = 0
+    got = m.forward_logits(tok)
+    want = msa_forward(sd, ocfg, tok)
+    assert np.abs(got - want).max() < BF16_TOL
 
 
 def test_msa_generate_draws_replay_exactly():
