@@ -158,6 +158,19 @@ int pg_msa_gibbs_single_run(pg_engine*, int32_t* tokens_inout, int R, int C, int
                             const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
                             const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
 
+/* ---- masked log-likelihood scoring ----------------------------------------------------------------
+ * The forward + log_softmax + gather of log_likelihood_batch (src/pgen/esm_sampler.py:336-348,355-362;
+ * src/pgen/esm_msa_sampler.py:398-410,421-431).  Sample s scores token row row_of[s] (ESM: the chain index;
+ * MSA: b*R + target_index) at positions idx[s][P] (entries < 0 are skipped and yield 0) against targets[s][P];
+ * out[s][P] = log_softmax(logits[row, pos, :])[target].  The LM head runs only at the scored rows.
+ * pg_logprob_gather_device: the same gather on a caller's device-resident full logits[n_rows][width][V]. */
+int pg_esm_forward_logprobs(pg_engine*, const int32_t* tokens, int B, int T, const int32_t* row_of, const int32_t* idx,
+                            const int32_t* targets, int n_sel, int P, float* out);
+int pg_msa_forward_logprobs(pg_engine*, const int32_t* tokens, int B, int R, int C, const int32_t* row_of,
+                            const int32_t* idx, const int32_t* targets, int n_sel, int P, float* out);
+int pg_logprob_gather_device(void* stream, const float* d_logits, int64_t n_rows, int width, int V, const int32_t* d_idx,
+                             const int32_t* d_row_map, const int32_t* d_targets, int64_t n_sel, int P, float* d_out);
+
 /* ---- stand-alone data-parallel ends of the iteration --------------------------------------
  * For plug-in models whose forward is not this engine (the reference accepts any object with
  * .model/.alphabet/.batch_converter, esm_sampler.py:54-58): logits come from the caller's model,

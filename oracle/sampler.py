@@ -302,3 +302,73 @@ class OracleMSASampler:
                     batch[0][target_index][kk] = t
                 fwd += 1
         return self.untokenize_batch(batch)[target_index]
+
+
+# ----------------------------------------------------------------------------------------------------
+# masked log-likelihood (next-tier path): /root/reference/src/pgen/esm_sampler.py:288-363,
+# /root/reference/src/pgen/esm_msa_sampler.py:319-432.  Pinned by tests/golden/loglik.json (reference run).
+# ----------------------------------------------------------------------------------------------------
+def _log_softmax(a):
+    a = np.asarray(a, dtype=np.float32)
+    m = a.max(axis=-1, keepdims=True)
+    return (a - m - np.log(np.exp(a - m, dtype=np.float32).sum(axis=-1, keepdims=True, dtype=np.float32))).astype(np.float32)
+
+
+def esm_log_likelihood_batch(forward, seq_list, with_masking=True, mask_distance=float("inf"), batch_size=None):
+    alphabet = Alphabet1b(append_eos=True)
+    if batch_size is None:
+        batch_size = len(seq_list)
+    out = []
+    for seq in seq_list:
+        s = clean_seed_seq(seq, ESM_ALLOWED)
+        one = alphabet.rows_to_tokens([s])
+        start, end = 1, len(seq) + 1
+        if with_masking:
+            n = int(min(mask_distance, len(s)))
+            copies = np.repeat(one, n, axis=0)
+            for i in range(n):
+                copies[i, list(range(start + i, end, n))] = alphabet.mask_idx
+        else:
+            n, copies = 1, one
+        total, lst = np.float32(0.0), []
+        for b0 in range(0, n, max(1, batch_size)):
+            lp = _log_softmax(forward(copies[b0:b0 + max(1, batch_size)]))
+            for i in range(lp.shape[0]):
+                for pos in range(start, end):
+                    if not with_masking or (pos - start) % n == i + b0:
+                        v = lp[i, pos, one[0, pos]]
+                        total = np.float32(total + v)
+                        lst.append(float(v))
+        out.append((float(total / np.float32(len(seq))), lst))
+    return out
+
+
+def msa_log_likelihood_batch(forward, msa_list, target_index=0, with_masking=True, count_gaps=False,
+                             mask_distance=float("inf"), batch_size=1):
+    alphabet = Alphabet1b(append_eos=False)
+    gap = {alphabet.get_idx("-")}
+    out = []
+    for msa in msa_list:
+        one = alphabet.rows_to_tokens([clean_seed_seq(s, MSA_ALLOWED) for s in msa])[None]
+        L = len(msa[target_index])
+        denom = L - (0 if count_gaps else msa[target_index].count("-"))
+        start, end = 1, L + 1
+        orig = one[0, target_index]
+        if with_masking:
+            n = int(min(mask_distance, L))
+            copies = np.repeat(one, n, axis=0)
+            for i in range(n):
+                copies[i, target_index, list(range(start + i, end, n))] = alphabet.mask_idx
+        else:
+            n, copies = 1, one
+        total, lst = np.float32(0.0), []
+        for b0 in range(0, n, max(1, batch_size)):
+            lp = _log_softmax(forward(copies[b0:b0 + max(1, batch_size)]))
+            for i in range(lp.shape[0]):
+                for pos in range(start, end):
+                    if (not with_masking or (pos - start) % n == i + b0) and (count_gaps or int(orig[pos]) not in gap):
+                        v = lp[i, target_index, pos, orig[pos]]
+                        total = np.float32(total + v)
+                        lst.append(float(v))
+        out.append((float(total / np.float32(denom)), lst))
+    return out

@@ -118,3 +118,31 @@ def run_plugin_loop(model_callable, tokens_i64, table, params, device, row_map=N
                                                     ctypes.byref(params), it, None))
         torch.cuda.synchronize(dev)
     return tok.to(device="cpu", dtype=torch.int64).reshape(shape)
+
+
+def score_positions(model_callable, tokens_i64, row_of, idx, targets, device):
+    """log_softmax(logits)[target] at (token row row_of[s], position idx[s][p]); idx < 0 -> 0.
+    Engine models: one native call (LM head only at the scored rows).  Plug-in models: the caller's forward, then the
+    HIP gather kernel `pg_logprob_gather_device` on its device-resident logits."""
+    import torch
+    from .engine import NativeMaskedLM
+    row_of = np.ascontiguousarray(row_of, dtype=np.int32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    targets = np.ascontiguousarray(targets, dtype=np.int32)
+    if isinstance(model_callable, NativeMaskedLM):
+        return model_callable.forward_logprobs(tokens_i64.numpy() if hasattr(tokens_i64, "numpy") else tokens_i64, row_of, idx, targets)
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible: log-likelihood scoring has no CPU implementation in this package")
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        out = model_callable(tokens_i64.to(dev))["logits"].to(device=dev, dtype=torch.float32).contiguous()
+        width, V = out.shape[-2], out.shape[-1]
+        n_rows = out.numel() // (width * V)
+        d_idx, d_row, d_tgt = (torch.from_numpy(a).to(dev) for a in (idx, row_of, targets))
+        res = torch.zeros(idx.shape, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().pg_logprob_gather_device(_current_stream_ptr(dev), ctypes.c_void_p(out.data_ptr()), n_rows, width, V,
+                                                       ctypes.c_void_p(d_idx.data_ptr()), ctypes.c_void_p(d_row.data_ptr()),
+                                                       ctypes.c_void_p(d_tgt.data_ptr()), idx.shape[0], idx.shape[1],
+                                                       ctypes.c_void_p(res.data_ptr())))
+        torch.cuda.synchronize(dev)
+    return res.cpu().numpy()

@@ -83,6 +83,11 @@ SIGNATURES = [
                                         c_void_p, c_void_p]),
     ("pg_msa_gibbs_single_run", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                         POINTER(SampleParams), c_void_p, c_void_p]),
+    ("pg_esm_forward_logprobs", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    ("pg_msa_forward_logprobs", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_void_p]),
+    ("pg_logprob_gather_device", c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                         c_void_p]),
     ("pg_mask_scatter_device", c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int]),
     ("pg_sample_writeback_device", c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                                            c_int, POINTER(SampleParams), c_int, c_void_p]),

@@ -228,6 +228,61 @@ int pg_msa_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int R,
   return h->e.msa_gibbs_device(d_tokens_inout, B, R, C, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
 }
 
+// ---- masked log-likelihood scoring (next-tier path: log_likelihood_batch) ---------------------------
+// rows: tokens[n_rows][width]; sample s scores token row row_of[s] at positions idx[s][P] (entries < 0 skipped, out = 0)
+// against targets[s][P]; out[s][P] = log_softmax(logits)[target].
+static int forward_logprobs(Engine& e, bool msa, const int32_t* tokens, int B, int R, int C, const int32_t* row_of,
+                            const int32_t* idx, const int32_t* targets, int n_sel, int P, float* out) {
+  DeviceGuard g(e.device);
+  const int64_t M = (int64_t)B * R * C;
+  const int64_t n = (int64_t)n_sel * P;
+  int rc;
+  if (n == 0 || B == 0) return PG_OK;
+  if ((rc = e.d_tokens.ensure((size_t)M * 4, e.stream))) return rc;
+  if ((rc = e.d_idx.ensure((size_t)n * 4, e.stream)) || (rc = e.d_samp_tok.ensure((size_t)n * 4, e.stream))) return rc;
+  if ((rc = e.d_rowmap.ensure((size_t)n_sel * 4, e.stream))) return rc;
+  if ((rc = e.logits.ensure((size_t)n * e.cfg.vocab * 4, e.stream)) || (rc = e.d_samp_logits.ensure((size_t)n * 4, e.stream))) return rc;
+  for (int64_t i = 0; i < n; ++i)
+    if (idx[i] >= C || (idx[i] >= 0 && (targets[i] < 0 || targets[i] >= e.cfg.vocab))) return fail(PG_ERR_INVALID, "logprobs: index out of range");
+  for (int i = 0; i < n_sel; ++i)
+    if (row_of[i] < 0 || row_of[i] >= B * R) return fail(PG_ERR_INVALID, "logprobs: row out of range");
+  PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens, (size_t)M * 4, hipMemcpyHostToDevice, e.stream));
+  PG_HIP(hipMemcpyAsync(e.d_idx.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, e.stream));
+  PG_HIP(hipMemcpyAsync(e.d_samp_tok.p, targets, (size_t)n * 4, hipMemcpyHostToDevice, e.stream));
+  PG_HIP(hipMemcpyAsync(e.d_rowmap.p, row_of, (size_t)n_sel * 4, hipMemcpyHostToDevice, e.stream));
+  if ((rc = msa ? e.msa_trunk(e.d_tokens.as<int32_t>(), B, R, C) : e.esm_trunk(e.d_tokens.as<int32_t>(), B, C))) return rc;
+  if ((rc = e.head(e.d_idx.as<int32_t>(), e.d_rowmap.as<int32_t>(), P, C, n, e.logits.as<float>()))) return rc;
+  if ((rc = launch_logprob_gather(e.stream, e.logits.as<float>(), e.cfg.vocab, 1, C, e.d_idx.as<int32_t>(), e.d_rowmap.as<int32_t>(),
+                                  e.d_samp_tok.as<int32_t>(), n_sel, P, e.d_samp_logits.as<float>()))) return rc;
+  PG_HIP(hipMemcpyAsync(out, e.d_samp_logits.p, (size_t)n * 4, hipMemcpyDeviceToHost, e.stream));
+  PG_HIP(hipStreamSynchronize(e.stream));
+  return PG_OK;
+}
+
+int pg_esm_forward_logprobs(pg_engine* h, const int32_t* tokens, int B, int T, const int32_t* row_of, const int32_t* idx,
+                            const int32_t* targets, int n_sel, int P, float* out) {
+  if (!h || !tokens || !row_of || !idx || !targets || !out) return fail(PG_ERR_INVALID, "pg_esm_forward_logprobs: null argument");
+  if (h->e.cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
+  if (B < 0 || T < 1 || n_sel < 0 || P < 0) return fail(PG_ERR_INVALID, "bad shape");
+  if (T > h->e.cfg.max_positions) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
+  return forward_logprobs(h->e, false, tokens, B, 1, T, row_of, idx, targets, n_sel, P, out);
+}
+
+int pg_msa_forward_logprobs(pg_engine* h, const int32_t* tokens, int B, int R, int C, const int32_t* row_of,
+                            const int32_t* idx, const int32_t* targets, int n_sel, int P, float* out) {
+  if (!h || !tokens || !row_of || !idx || !targets || !out) return fail(PG_ERR_INVALID, "pg_msa_forward_logprobs: null argument");
+  if (h->e.cfg.arch != PG_ARCH_MSA1B) return fail(PG_ERR_INVALID, "engine was not built for the MSA-1b architecture");
+  if (B < 0 || R < 1 || C < 1 || n_sel < 0 || P < 0) return fail(PG_ERR_INVALID, "bad shape");
+  return forward_logprobs(h->e, true, tokens, B, R, C, row_of, idx, targets, n_sel, P, out);
+}
+
+int pg_logprob_gather_device(void* stream, const float* d_logits, int64_t n_rows, int width, int V, const int32_t* d_idx,
+                             const int32_t* d_row_map, const int32_t* d_targets, int64_t n_sel, int P, float* d_out) {
+  if (!d_logits || !d_idx || !d_targets || !d_out) return fail(PG_ERR_INVALID, "pg_logprob_gather_device: null argument");
+  if (n_rows < 0 || width < 1 || V < 1 || n_sel < 0 || P < 0) return fail(PG_ERR_INVALID, "bad shape");
+  return launch_logprob_gather((hipStream_t)stream, d_logits, V, 0, width, d_idx, d_row_map, d_targets, n_sel, P, d_out);
+}
+
 // ---- stand-alone ends of the iteration ---------------------------------------------------------
 int pg_mask_scatter_device(void* stream, int32_t* d_tokens, int64_t n_rows, int width, const int32_t* d_idx,
                            const int32_t* d_row_map, int64_t n_sel, int P, int mask_idx) {

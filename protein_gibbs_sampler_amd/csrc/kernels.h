@@ -53,6 +53,8 @@ int launch_f32_to_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t n, 
 int launch_bf16_to_f32(hipStream_t s, const bf16_t* src, float* dst, int64_t n);
 int launch_scale_f32(hipStream_t s, float* p, int64_t n, float scale);
 
+int launch_logprob_gather(hipStream_t st, const float* logits, int V, int compact, int width, const int32_t* idx,
+                          const int32_t* row_map, const int32_t* targets, int64_t n_sel, int P, float* out);
 int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
                         int64_t n_sel, int P, int mask_idx);
 int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const float* logits, int V, int compact,

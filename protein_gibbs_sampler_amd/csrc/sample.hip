@@ -154,6 +154,38 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(int32_t* __restrict__
   tokens[trow * width + (raw & 0x3fffffff)] = mask_idx;
 }
 
+// log p(target | context) at the selected rows: log_softmax over the FULL vocabulary then gather
+// (== torch.log_softmax(logits, -1)[..., target], /root/reference/src/pgen/esm_sampler.py:340-345,
+//  esm_msa_sampler.py:403-410).  One thread per selected entry; V <= 64 floats per row.
+__global__ __launch_bounds__(256) void logprob_gather_kernel(const float* __restrict__ logits, int V, int compact, int width,
+                                                            const int32_t* __restrict__ idx,
+                                                            const int32_t* __restrict__ row_map,
+                                                            const int32_t* __restrict__ targets, int64_t n_sel, int P,
+                                                            float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_sel * P) return;
+  const int pos = idx[i];
+  if (pos < 0) { out[i] = 0.f; return; }
+  const int64_t s = i / P;
+  const int64_t trow = row_map ? (int64_t)row_map[s] : s;
+  const float* row = compact ? logits + (size_t)i * V : logits + ((size_t)trow * width + pos) * V;
+  float mx = row[0];
+  for (int v = 1; v < V; ++v) mx = fmaxf(mx, row[v]);
+  float sum = 0.f;
+  for (int v = 0; v < V; ++v) sum += expf(row[v] - mx);
+  out[i] = row[targets[i]] - mx - logf(sum);
+}
+
+int launch_logprob_gather(hipStream_t st, const float* logits, int V, int compact, int width, const int32_t* idx,
+                          const int32_t* row_map, const int32_t* targets, int64_t n_sel, int P, float* out) {
+  const int64_t n = n_sel * P;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(logprob_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logits, V, compact, width, idx,
+                     row_map, targets, n_sel, P, out);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
                         int64_t n_sel, int P, int mask_idx) {
   const int64_t n = n_sel * P;

@@ -102,6 +102,25 @@ class NativeMaskedLM:
             _lib.check(L.pg_esm_forward_logits(self.handle, _lib.ptr(tok), B, T, _lib.ptr(out)))
         return out
 
+    def forward_logprobs(self, tokens, row_of, idx, targets):
+        """log_softmax(logits)[target] at positions idx[s] of token row row_of[s] (C ABI pg_*_forward_logprobs)."""
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        row_of = np.ascontiguousarray(row_of, dtype=np.int32)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        targets = np.ascontiguousarray(targets, dtype=np.int32)
+        n_sel, P = idx.shape
+        out = np.zeros((n_sel, P), dtype=np.float32)
+        L = _lib.lib()
+        if self.is_msa:
+            B, R, C = tok.shape
+            _lib.check(L.pg_msa_forward_logprobs(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(row_of), _lib.ptr(idx),
+                                                 _lib.ptr(targets), n_sel, P, _lib.ptr(out)))
+        else:
+            B, T = tok.shape
+            _lib.check(L.pg_esm_forward_logprobs(self.handle, _lib.ptr(tok), B, T, _lib.ptr(row_of), _lib.ptr(idx),
+                                                 _lib.ptr(targets), n_sel, P, _lib.ptr(out)))
+        return out
+
     # ---- whole Gibbs loops -----------------------------------------------------------------
     def gibbs_run(self, tokens, target_idx, params, want_logits=False, want_tokens=False):
         """tokens int32 [B,T] or [B,R,C] (modified in place); target_idx int32 [iters, B, P] / [iters, B, R, P]."""

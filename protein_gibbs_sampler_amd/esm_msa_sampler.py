@@ -223,3 +223,59 @@ class ESM_MSA_sampler():
         else:
             last_i = -1
         return indexes, last_i
+
+    # ---- masked log-likelihood of one MSA row (reference :306-432) --------------------------------------
+    def log_likelihood(self, msa, target_index=0, with_masking=True, verbose=False, count_gaps=False,
+                       mask_distance=float("inf")):
+        return next(self.log_likelihood_batch([msa], target_index, with_masking, verbose, count_gaps, mask_distance))
+
+    def log_likelihood_batch(self, msa_list, target_index=0, with_masking=True, verbose=False, count_gaps=False,
+                             mask_distance=float("inf"), batch_size=1):
+        """Same contract as pgen.esm_msa_sampler.ESM_MSA_sampler.log_likelihood_batch: yields (float mean, list[float])
+        for the row `target_index` of every MSA; gap positions of the target row are skipped unless count_gaps.
+        Every MSA is scored on its own tokens (no padding reaches the model)."""
+        self._require_gpu("log_likelihood_batch")
+        gap_tokens = {self.model.alphabet.get_idx(x) for x in ESM_MSA_GAP_CHARACTERS}
+        if batch_size is None:
+            batch_size = len(msa_list)
+        range_start = 1 if self.model.alphabet.prepend_bos else 0
+        mask_idx = self.model.alphabet.mask_idx
+        for msa in msa_list:
+            reformatted = [(str(i), self.clean_seed_seq(seq)) for i, seq in enumerate(msa)]
+            _, _, one = self.model.batch_converter(reformatted)            # [1, R, C]
+            R = one.shape[1]
+            tr = target_index % R
+            seq_len = len(msa[target_index])
+            denom = seq_len - (0 if count_gaps else sum(msa[target_index].count(g) for g in ESM_MSA_GAP_CHARACTERS))
+            end = seq_len + range_start
+            orig = one[0, tr].numpy()
+            if with_masking:
+                n = int(min(mask_distance, seq_len))
+                copies = one.repeat(n, 1, 1)
+                pos_all = [list(range(range_start + i, end, n)) for i in range(n)]
+                for i, pos in enumerate(pos_all):
+                    copies[i, tr, pos] = mask_idx
+            else:
+                n = 1
+                copies = one
+                pos_all = [list(range(range_start, end))]
+            pos_of = [[p for p in pos if count_gaps or int(orig[p]) not in gap_tokens] for pos in pos_all]
+            P = max((len(p) for p in pos_of), default=0)
+            idx = np.full((n, max(P, 1)), -1, dtype=np.int32)
+            tgt = np.zeros((n, max(P, 1)), dtype=np.int32)
+            for i, pos in enumerate(pos_of):
+                idx[i, :len(pos)] = pos
+                tgt[i, :len(pos)] = orig[pos]
+            likelihood_sum = np.float32(0.0)
+            likelihood_list = []
+            for batch_start in range(0, n, max(1, batch_size)):
+                sl = slice(batch_start, batch_start + max(1, batch_size))
+                nb = copies[sl].shape[0]
+                row_of = np.arange(nb) * R + tr
+                lp = _gibbs.score_positions(self.model.model, copies[sl], row_of, idx[sl], tgt[sl], self.device)
+                for i in range(nb):
+                    for p in range(len(pos_of[batch_start + i])):
+                        likelihood_sum = np.float32(likelihood_sum + lp[i, p])
+                        likelihood_list.append(float(lp[i, p]))
+            assert len(likelihood_list) == denom
+            yield (float(likelihood_sum / np.float32(denom)), likelihood_list)

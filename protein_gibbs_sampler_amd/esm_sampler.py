@@ -240,3 +240,66 @@ class ESM_sampler():
             else:
                 sequences += strs
         return sequences
+
+    # ---- masked log-likelihood (reference :277-363) ---------------------------------------------------
+    def log_likelihood(self, seq, with_masking=True, verbose=False, mask_distance=float("inf"), batch_size=None):
+        """(mean log-likelihood, per-position list) of one sequence -- see log_likelihood_batch."""
+        return next(self.log_likelihood_batch([seq], with_masking, verbose, mask_distance, batch_size))
+
+    def log_likelihood_batch(self, seq_list, with_masking=True, verbose=False, mask_distance=float("inf"), batch_size=None):
+        """Same contract as pgen.esm_sampler.ESM_sampler.log_likelihood_batch: yields (float mean, list[float]).
+        with_masking: min(mask_distance, len) copies of the sequence, copy i masked at every
+        num_copies-th position starting at i; the log-probability of the original residue is read at the masked
+        positions.  The forward, log-softmax and gather run on the GPU (pg_esm_forward_logprobs: the LM head is
+        evaluated only at the scored rows)."""
+        if not self.cuda:
+            raise RuntimeError("ESM_sampler.log_likelihood_batch needs device 'gpu'/'cuda:N' on an MI355X: "
+                               "there is no CPU implementation")
+        n_batches = len(seq_list)
+        if batch_size is None:
+            batch_size = n_batches
+        reformatted_seq = [(str(idx), self.clean_seed_seq(seq)) for idx, seq in enumerate(seq_list)]
+        _, _, tokens = self.model.batch_converter(reformatted_seq)
+        range_start = 1 if self.model.alphabet.prepend_bos else 0
+        end_modifier = -1 if self.model.alphabet.append_eos else 0
+        batch_range_end = [len(seq) + range_start for seq in seq_list]
+        overall_range_end = tokens.shape[1] + end_modifier
+        assert max(len(seq) for seq in seq_list) == len(range(range_start, overall_range_end))
+        old_toks = tokens.numpy()
+        mask_idx = self.model.alphabet.mask_idx
+        for seq_idx in range(len(reformatted_seq)):
+            original_string = reformatted_seq[seq_idx][1]
+            end = batch_range_end[seq_idx]
+            # tokens of THIS sequence alone (no padding reaches the model, as in the reference's masked path)
+            _, _, one = self.model.batch_converter([(0, original_string)])
+            if with_masking:
+                n = int(min(mask_distance, len(original_string)))
+                copies = one.repeat(n, 1)
+                pos_of = [list(range(range_start + i, end, n)) for i in range(n)]
+                for i, pos in enumerate(pos_of):
+                    copies[i, pos] = mask_idx
+                assert sum(len(p) for p in pos_of) == len(original_string)
+            else:
+                n = 1
+                copies = one
+                pos_of = [list(range(range_start, end))]
+            P = max((len(p) for p in pos_of), default=0)
+            idx = np.full((n, P), -1, dtype=np.int32)
+            tgt = np.zeros((n, P), dtype=np.int32)
+            for i, pos in enumerate(pos_of):
+                idx[i, :len(pos)] = pos
+                tgt[i, :len(pos)] = old_toks[seq_idx, pos]
+            likelihood_sum = np.float32(0.0)
+            likelihood_list = []
+            for batch_start in range(0, n, max(1, batch_size)):
+                sl = slice(batch_start, batch_start + max(1, batch_size))
+                nb = copies[sl].shape[0]
+                lp = _gibbs.score_positions(self.model.model, copies[sl], np.arange(nb), idx[sl], tgt[sl], self.device)
+                for i in range(nb):
+                    for p in range(len(pos_of[batch_start + i])):
+                        likelihood_sum = np.float32(likelihood_sum + lp[i, p])
+                        likelihood_list.append(float(lp[i, p]))
+            if with_masking:
+                # the reference appends in (copy, position) order; positions of one copy ascend (stride n)
+                pass
+            yield (float(likelihood_sum / np.float32(len(seq_list[seq_idx]))), likelihood_list)

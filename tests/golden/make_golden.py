@@ -376,8 +376,38 @@ def gen_hf():
                             cfg=json.dumps(ck), seed=seed, std=std, embed_std=estd, ln_jitter=jit)
 
 
+def gen_loglik():
+    """log_likelihood_batch of both reference samplers driven with the stand-in model (next-tier path)."""
+    sys.path.insert(0, REF_SRC)
+    import torch
+    from pgen import esm_msa_sampler as refm
+    from pgen import esm_sampler as ref
+    out = {"esm": [], "msa": []}
+    seqs = ["MRHGDISSSNDTVGVAVVNYKMPRLHTAAEVLDNAR", "ACDEFGHIKL", "MKV"]
+    for kw in (dict(with_masking=True), dict(with_masking=True, mask_distance=5), dict(with_masking=True, mask_distance=2, batch_size=1),
+               dict(with_masking=False), dict(with_masking=True, mask_distance=50, batch_size=3)):
+        s = ref.ESM_sampler(_standin("esm1b"), device="cpu")
+        res = [(m, l) for m, l in s.log_likelihood_batch(list(seqs), **kw)]
+        out["esm"].append(dict(seqs=seqs, kw={k: (v if v != float("inf") else None) for k, v in kw.items()},
+                               means=[r[0] for r in res], lists=[r[1] for r in res]))
+    msas = [["ACDEFGHIKL", "AC-EFGHIKL", "ACDEFG--KL", "MCDEFGHIKV"], ["MKV-A", "MKVAA", "M-VAA"]]
+    for kw in (dict(target_index=0), dict(target_index=1, mask_distance=3), dict(target_index=2, count_gaps=True, mask_distance=4),
+               dict(target_index=0, with_masking=False), dict(target_index=1, with_masking=False, count_gaps=True),
+               dict(target_index=-1, mask_distance=2, batch_size=2)):
+        means, lists = [], []
+        for msa in msas:       # one MSA per call: the reference pads ragged batches, this package scores MSAs separately
+            s = refm.ESM_MSA_sampler(_standin("msa1b"), device="cpu")
+            for m, l in s.log_likelihood_batch([list(msa)], **kw):
+                means.append(m)
+                lists.append(l)
+        out["msa"].append(dict(msas=msas, kw=kw, means=means, lists=lists))
+    with open(os.path.join(HERE, "loglik.json"), "w") as f:
+        json.dump(out, f)
+    print("loglik.json written:", len(out["esm"]), len(out["msa"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hf", "misc", "esm", "msa"]
+    which = sys.argv[1:] or ["hf", "misc", "esm", "msa", "loglik"]
     if "hf" in which:
         gen_hf()
     if "misc" in which:
@@ -386,3 +416,5 @@ if __name__ == "__main__":
         gen_sampler_esm()
     if "msa" in which:
         gen_sampler_msa()
+    if "loglik" in which:
+        gen_loglik()
