@@ -1,0 +1,110 @@
+"""On-disk formats and CLI plumbing (host-only parts run on CPU; the end-to-end CLI run is a GPU test).
+Cases follow the reference's utils tests (/root/reference/test/test_utils.py:27-100)."""
+import io
+import warnings
+
+import pytest
+
+from protein_gibbs_sampler_amd import _cli, fasta_io, pgen_esm, pgen_msa
+
+A2M = """
+>seq_1
+mdgtrtsldieeysdtevqknqvlTLEEWQDKWVNGKTAFHQEQGHQLLKKHLDTflKGKSGLRVFFPLCGKAVEMKWFADRGHSVVGVEISELGIQEFFTEQNLSYSeep*
+>seq_2 some description
+........................TLEEWQDKWVNGKTAFHQEQGHQLLKKHLDT..KGKSGLRVFFPLCGKAVEMKWFADRGHSVVGVEISELGIQEFFTEQNLSYS...*
+>seq_3
+mdgtrtsldieeysdtevqknqvlTLEEWQDKWVNGK
+TAFHQEQGHQLLKKHLDTflKGKSGLRVFFPLCGKAV
+EMKWFADRGHSVVGVEISELGIQEFFTEQNLSYSeep*
+
+"""
+CORE = "TLEEWQDKWVNGKTAFHQEQGHQLLKKHLDTKGKSGLRVFFPLCGKAVEMKWFADRGHSVVGVEISELGIQEFFTEQNLSYS"
+
+
+def test_parse_fasta_modes():
+    names, seqs = fasta_io.parse_fasta(io.StringIO(A2M), return_names=True)
+    assert names == ["seq_1", "seq_2", "seq_3"] and seqs[0] == seqs[2] and seqs[1].startswith("........")
+    assert fasta_io.parse_fasta(io.StringIO(A2M), return_names=True, full_name=True)[0][1] == "seq_2 some description"
+    assert fasta_io.parse_fasta(io.StringIO(A2M), clean="delete") == [CORE] * 3
+    up = fasta_io.parse_fasta(io.StringIO(A2M), clean="upper")
+    assert up[0].startswith("MDGTRTSLDIEEYSDTEVQKNQVLTLEEW") and up[1].startswith("-" * 24 + "TLEEW") and "*" not in up[0]
+    assert len(set(len(s) for s in up)) == 1
+    un = fasta_io.parse_fasta(io.StringIO(A2M), clean="unalign")
+    assert un[1] == CORE and un[0].startswith("MDGTRTS")
+    with pytest.raises(ValueError):
+        fasta_io.parse_fasta(io.StringIO(A2M), clean="bogus")
+
+
+def test_write_sequential_fasta_roundtrip(tmp_path):
+    p = tmp_path / "x.fasta"
+    fasta_io.write_sequential_fasta(p, ["ACD", "EF<mask>G"])
+    assert p.read_text() == ">0\nACD\n>1\nEF<mask>G\n"
+    assert fasta_io.parse_fasta(p, return_names=True) == (["0", "1"], ["ACD", "EF<mask>G"])
+
+
+@pytest.mark.parametrize("kw,expected", [
+    (dict(n=1, keep_first=True, strategy="in_order"), [0]), (dict(n=1, keep_first=False, strategy="in_order"), [0]),
+    (dict(n=1, keep_first=True, strategy="random"), [0]), (dict(n=3, keep_first=True, strategy="in_order"), [0, 1, 2]),
+    (dict(n=3, keep_first=False, strategy="in_order"), [0, 1, 2]), (dict(n=0, keep_first=False, strategy="in_order"), []),
+    (dict(n=0, keep_first=True, strategy="in_order"), []), (dict(n=5000, keep_first=True, strategy="in_order"), [0, 1, 2, 3, 4, 5]),
+    (dict(n=5000, keep_first=False, strategy="in_order"), [0, 1, 2, 3, 4, 5])])
+def test_subsetter(kw, expected):
+    assert fasta_io.SequenceSubsetter.subset([0, 1, 2, 3, 4, 5], **kw) == expected
+
+
+def test_subsetter_random():
+    out = fasta_io.SequenceSubsetter.subset([0, 1, 2, 3, 4, 5], 5000, keep_first=True, strategy="random", random_seed=1)
+    assert out[0] == 0 and set(out) == {0, 1, 2, 3, 4, 5} and out != [0, 1, 2, 3, 4, 5]
+    with pytest.raises(ValueError):
+        fasta_io.SequenceSubsetter.subset([1, 2], 1, strategy="bogus")
+
+
+def test_parse_line_args_is_literal_only():
+    d = _cli.parse_line_args("{'seed_seq': 'MEPAATGQEAEECAHSGRGEAWEEV', 'num_iters': 20, 'burnin': 10, 'mask': True, 'in_order':False, "
+                             "'num_positions_percent': 10, 'top_k': 1}")
+    assert d["num_iters"] == 20 and d["mask"] is True and d["top_k"] == 1
+    assert _cli.parse_line_args("{'burnin': float('inf'), 'temperature': None}") == {"burnin": float("inf"), "temperature": None}
+    assert _cli.parse_line_args("{'burnin': inf}")["burnin"] == float("inf")
+    with pytest.raises(Exception):
+        _cli.parse_line_args("__import__('os').system('true')")
+
+
+def test_cli_surface_matches_reference_flags():
+    e = pgen_esm.build_parser().parse_args(["-o", "out", "-i", "spec.tsv", "--batch_size", "4", "--num_output_sequences", "8",
+                                            "--device", "cuda:0", "--model", "esm1b"])
+    assert (e.o, e.i, e.batch_size, e.num_output_sequences, e.device, e.model) == ("out", "spec.tsv", 4, 8, "cuda:0", "esm1b")
+    m = pgen_msa.build_parser().parse_args(["--alignment_size", "32", "--keep_first_sequence", "--subset_strategy", "in_order",
+                                            "--delete_insertions"])
+    assert m.alignment_size == 32 and m.keep_first_sequence and m.subset_strategy == "in_order" and m.delete_insertions
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path, monkeypatch):
+    """TSV in -> specification.tsv echo + <name>.fasta with records 0..n-1 of the right length and alphabet."""
+    from protein_gibbs_sampler_amd import models, weights
+    small_esm = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=2, d_ffn=256, max_positions=64)
+    small_msa = weights.make_config(weights.MSA1B_CONFIG, d_model=128, n_layers=2, d_ffn=256, max_positions=64, max_msa_rows=16)
+    monkeypatch.setitem(pgen_esm.model_map, "esm1b", lambda **k: models.ESM1b(config=small_esm, **k))
+    monkeypatch.setitem(pgen_msa.model_map, "esm_msa1", lambda **k: models.ESM_MSA1(config=small_msa, **k))
+    spec = tmp_path / "spec.tsv"
+    spec.write_text("first\t{'seed_seq': 'MEPAATGQEAEECAHSGRGEAWEEV', 'num_iters': 3, 'burnin': 2, 'num_positions_percent': 10, 'top_k': 1}\n"
+                    "\nbad line without tab\n"
+                    "second\t{'seed_seq': 'ACDEFGHIKL', 'max_len': 14, 'num_iters': 2}\n")
+    out = tmp_path / "out"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pgen_esm.cli(["-i", str(spec), "-o", str(out), "--num_output_sequences", "5", "--batch_size", "2", "--seed", "3"])
+    assert (out / "specification.tsv").read_text().count("\n") == 2
+    names, seqs = fasta_io.parse_fasta(out / "first.fasta", return_names=True)
+    assert names == [str(i) for i in range(5)] and all(len(s) == 25 and set(s) <= set("ACDEFGHIKLMNPQRSTVWY") for s in seqs)
+    assert len(fasta_io.parse_fasta(out / "second.fasta")) == 5
+    msa = tmp_path / "seed.a2m"
+    msa.write_text(">a\nACDEFGHIKLmn\n>b\nAC-EFGHIKL..\n>c\nACDEFG--KLmn\n>d\nMCDEFGHIKVmn\n")
+    spec2 = tmp_path / "spec2.tsv"
+    spec2.write_text("m1\t{'num_iters': 2, 'num_positions': 2}\t%s\n" % msa)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pgen_msa.cli(["-i", str(spec2), "-o", str(out), "--num_output_sequences", "6", "--alignment_size", "3",
+                      "--keep_first_sequence", "--delete_insertions", "--seed", "1"])
+    seqs = fasta_io.parse_fasta(out / "m1.fasta")
+    assert len(seqs) == 6 and all(len(s) == 10 and set(s) <= set("-ACDEFGHIKLMNPQRSTVWY") for s in seqs)
