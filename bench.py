@@ -48,6 +48,21 @@ def total_flops_per_iter(cfg, n_tokens, T, n_sampled):
     return gemm_flops_per_iter(cfg, n_tokens, n_sampled) + cfg["n_layers"] * 4.0 * T * d * n_tokens + 2.0 * V * d * n_sampled
 
 
+def measured_gemm_traffic():
+    """Fabric (L2 -> Infinity Cache/HBM) bytes per GEMM launch from the committed PMC passes
+    (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, calibrated on the LayerNorm
+    kernel whose traffic is known exactly).  None when the profile file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+    if not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"]
+    gem = [(v["launches"], v["read_MB_per_launch"] + v["write_MB_per_launch"]) for n, v in k.items()
+           if "gemm_bf16_pp_kernel<0" in n or "gemm_bf16_pp_kernel<1" in n or "gemm_bf16_pp_kernel<2" in n]
+    if not gem:
+        return None
+    return 1e6 * sum(n * mb for n, mb in gem) / sum(n for n, _ in gem)
+
+
 def cpu_baseline(cfg, sd, B, L, P, valid_idx, target_seconds=15.0):
     """Times the CPU oracle (checker, never the product) on a bounded sample of the same workload:
     b chains x one full Gibbs iteration (mask, fp32 forward, draw).  Scales linearly in chains."""
@@ -198,7 +213,9 @@ def main():
             achieved = gf / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all %d launches/iteration)" % (launches // n_prof),
                                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_gemm_traffic(),
+                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated), avg over the 4 per-layer GEMMs; "
+                                               "algorithmic minimum 0.63 GB/launch -- the excess is X/W panel re-reads served by the 256 MB Infinity Cache",
                                "avg_launch_ms": ms / launches, "flops_per_launch": gf / launches}
             out["time_split_ms_per_iter"] = {c: v[0] / n_prof for c, v in parts.items()}
     if rank == 0 and not args.no_cpu_baseline:

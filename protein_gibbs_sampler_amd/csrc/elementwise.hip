@@ -203,6 +203,20 @@ __global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __rest
   store_row_bf16(h + (size_t)r * d, v, nch4, lane, h_lo ? h_lo + (size_t)r * d : nullptr);
 }
 
+// ---- plain row gathers (last-layer pruning: only the sampled rows go through out-proj / FFN of the final layer) ----
+// dst[r] = src[row_of(r) * width + idx[r]] for 16-byte chunks; idx < 0 -> row 0 (value never read back)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                         const int32_t* __restrict__ idx, const int32_t* __restrict__ row_map,
+                                                         int P, int width, int64_t n_sel, int chunks) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_sel) return;
+  int pos = idx[r];
+  pos = pos < 0 ? 0 : (pos & 0x3fffffff);
+  const int64_t s = r / P;
+  const int64_t row = (row_map ? (int64_t)row_map[s] : s) * width + pos;
+  for (int c = threadIdx.x & 63; c < chunks; c += 64) dst[r * chunks + c] = src[row * chunks + c];
+}
+
 // ---- LM-head tail: logits[r][V] = LN(g[r]) . embed^T + bias ----------------------------------
 // g = gelu(dense(x)) fp32 [n][d] (GEMM epilogue); the 33 x d tied decoder stays L2-resident.
 __global__ __launch_bounds__(256) void lm_tail_kernel(const float* __restrict__ g, const float* __restrict__ gamma,
@@ -316,6 +330,16 @@ int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, con
   if (n_sel == 0) return 0;
   hipLaunchKernelGGL(gather_ln_bf16_kernel, dim3(rows_grid(n_sel)), dim3(256), 0, s, x, idx, row_map, P, width, gamma,
                      beta, h, h_lo, n_sel, d, eps);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gather_rows(hipStream_t s, const void* src, void* dst, const int32_t* idx, const int32_t* row_map, int P, int width,
+                       int64_t n_sel, int row_bytes) {
+  if (n_sel == 0) return 0;
+  if (row_bytes % 16) return fail(1, "gather: rows must be multiples of 16 bytes");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_grid(n_sel)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, idx, row_map, P,
+                     width, n_sel, row_bytes / 16);
   PG_HIP(hipGetLastError());
   return 0;
 }

@@ -65,6 +65,7 @@ struct Engine {
   // workspace (grow-only)
   DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
   // strict precision mode (PG_PREC_FP32): lo halves of the split-bf16 operands, fp32 GEMM outputs, row-attention scores
+  DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
   DevBuf h_lo, ctx_lo, ffn_lo, ffn_f32, sel_h_lo, scores, zero_bias;
   bool strict() const { return precision == PG_PREC_FP32; }
   // out[Mp][N] fp32 (=|+=) X.W^T + b with X = xh + xl, W = w + w_lo:  xh.w + xh.w_lo + xl.w  (three MFMA GEMMs)
@@ -75,8 +76,12 @@ struct Engine {
   int init(const pg_model_config* c, const pg_tensor* tensors, int n_tensors, int device_ordinal, int precision);
 
   // ---- forward pieces (all on `stream`, device pointers) ----
-  int esm_trunk(const int32_t* d_tok, int B, int T);                         // tokens -> x (before ln_after)
-  int head(const int32_t* d_idx, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits);
+  // tokens -> x (before ln_after).  With a selection (sel_idx != nullptr, bf16 mode) the LAST layer's out-proj, LN2 and
+  // FFN run only on the selected rows and x_sel [n_sel][d] holds their residual stream (exact: nothing else reads
+  // the last layer's output); head_compact() then consumes x_sel.
+  int esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx = nullptr, int P = 0, int64_t n_sel = 0);
+  int head(const int32_t* d_idx, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits,
+           const float* x_src = nullptr);
   int esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp,
                        float* d_samp_logits, int32_t* d_samp_tok);
   int msa_trunk(const int32_t* d_tok, int B, int R, int C);                  // tokens[B][R][C] -> x

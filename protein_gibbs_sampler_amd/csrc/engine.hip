@@ -6,6 +6,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace pg {
@@ -87,7 +88,7 @@ Engine::~Engine() {
   if (device >= 0) (void)hipSetDevice(device);
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
-                    &d_rowmap, &scratch, &h_lo, &ctx_lo, &ffn_lo, &ffn_f32, &sel_h_lo, &scores, &zero_bias};
+                    &d_rowmap, &scratch, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &h_lo, &ctx_lo, &ffn_lo, &ffn_f32, &sel_h_lo, &scores, &zero_bias};
   for (DevBuf* b : bufs) b->release();
   prof.destroy();
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -241,7 +242,7 @@ int Engine::dense3(const bf16_t* xh, const bf16_t* xl, const DenseW& W, float* o
 // ------------------------------------------------------------------------------------------------
 // ESM-1b forward: tokens[B][T] -> x[B*T][d] (residual stream before emb_layer_norm_after)
 // ------------------------------------------------------------------------------------------------
-int Engine::esm_trunk(const int32_t* d_tok, int B, int T) {
+int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx, int P, int64_t n_sel) {
   const int d = cfg.d_model, f = cfg.d_ffn;
   const int64_t M = (int64_t)B * T;
   const int64_t Mp = round_up64(M, kRowPad);
@@ -300,6 +301,25 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T) {
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if ((rc = timed(PC_ATTN, [&] { return launch_attention_bf16(stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d); }))) return rc;
+    if (sel_idx && l == cfg.n_layers - 1) {
+      // last layer: only the selected rows are ever read again -> gather them and finish the layer on n_sel rows
+      const int64_t Np = round_up64(n_sel, kRowPad);
+      if ((rc = x_sel.ensure((size_t)Np * d * 4, stream)) || (rc = ctx_sel.ensure((size_t)Np * d * 2, stream)) ||
+          (rc = h_sel.ensure((size_t)Np * d * 2, stream)) || (rc = ffn_sel.ensure((size_t)Np * f * 2, stream))) return rc;
+      float* XS = x_sel.as<float>();
+      const int Ni = (int)Np;
+      rc = timed(PC_HEAD, [&] {
+        int r2 = launch_gather_rows(stream, X, XS, sel_idx, nullptr, P, T, n_sel, d * 4);
+        if (r2) return r2;
+        return launch_gather_rows(stream, CTX, ctx_sel.as<bf16_t>(), sel_idx, nullptr, P, T, n_sel, d * 2);
+      });
+      if (rc) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.out.w, L.out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln2.g, L.ln2.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID); }))) return rc;
+      break;
+    }
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
@@ -310,7 +330,9 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T) {
 
 // LM head evaluated ONLY at the selected rows: emb_layer_norm_after -> dense -> GELU ->
 // LayerNorm -> tied decoder + bias.  d_idx == nullptr: every one of the n_sel rows of x in order.
-int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits) {
+int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits,
+                 const float* x_src) {
+  if (!x_src) x_src = x.as<float>();
   const int d = cfg.d_model, V = cfg.vocab;
   const int64_t Np = round_up64(n_sel, kRowPad);
   int rc;
@@ -319,14 +341,14 @@ int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int wid
   const float eps = cfg.layer_norm_eps;
   if (strict()) {
     if ((rc = sel_h_lo.ensure((size_t)Np * d * 2, stream))) return rc;
-    if ((rc = launch_gather_ln_bf16(stream, x.as<float>(), d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
+    if ((rc = launch_gather_ln_bf16(stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
                                     sel_h.as<bf16_t>(), n_sel, d, eps, sel_h_lo.as<bf16_t>()))) return rc;
     if ((rc = dense3(sel_h.as<bf16_t>(), sel_h_lo.as<bf16_t>(), head_dense, sel_g.as<float>(), (int)Np, false))) return rc;
     if ((rc = launch_gelu_f32(stream, sel_g.as<float>(), Np * d))) return rc;
     return launch_lm_tail(stream, sel_g.as<float>(), head_ln.g, head_ln.b, embed, head_bias, d_logits, n_sel, d, V, eps);
   }
   return timed(PC_HEAD, [&] {
-    int r = launch_gather_ln_bf16(stream, x.as<float>(), d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
+    int r = launch_gather_ln_bf16(stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
                                   sel_h.as<bf16_t>(), n_sel, d, eps);
     if (r) return r;
     r = launch_gemm_bf16(stream, sel_h.as<bf16_t>(), head_dense.w, head_dense.b, sel_g.as<float>(), (int)Np, d, d, d, d, d,
@@ -351,10 +373,12 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
     const int32_t* idx_it = d_idx_ + (size_t)it * n_draws;
     if (sp->mask && P > 0)
       if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, T, idx_it, nullptr, n_sel_rows, P, sp->mask_idx); }))) return rc;
-    if ((rc = esm_trunk(d_tok, B, T))) return rc;
+    static const int prune = [] { const char* e = getenv("PGIBBS_PRUNE_LAST"); return e ? atoi(e) : 1; }();
+    const bool pruned = prune && !strict() && P > 0 && n_draws * 2 < (int64_t)B * T;
+    if ((rc = pruned ? esm_trunk(d_tok, B, T, idx_it, P, n_draws) : esm_trunk(d_tok, B, T))) return rc;
     if (P == 0) continue;
     float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)it * n_draws * V : logits.as<float>();
-    if ((rc = head(idx_it, nullptr, P, T, n_draws, lg))) return rc;
+    if ((rc = pruned ? head(nullptr, nullptr, 1, 1, n_draws, lg, x_sel.as<float>()) : head(idx_it, nullptr, P, T, n_draws, lg))) return rc;
     int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)it * n_draws : nullptr;
     if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, T, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, it, st); }))) return rc;
   }

@@ -47,6 +47,8 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx_hi, bf16_t
 // strict tied row attention; `scores` is an fp32 scratch of B*H*C*C floats
 int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx_hi, bf16_t* ctx_lo, int B, int R,
                                  int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale);
+int launch_gather_rows(hipStream_t s, const void* src, void* dst, const int32_t* idx, const int32_t* row_map, int P, int width,
+                       int64_t n_sel, int row_bytes);
 int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const float* beta, const float* embed,
                    const float* out_bias, float* logits, int64_t n, int d, int V, float eps);
 int launch_f32_to_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t n, float scale);
