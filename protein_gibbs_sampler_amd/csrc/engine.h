@@ -84,7 +84,10 @@ struct Engine {
            const float* x_src = nullptr);
   int esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp,
                        float* d_samp_logits, int32_t* d_samp_tok);
-  int msa_trunk(const int32_t* d_tok, int B, int R, int C);                  // tokens[B][R][C] -> x
+  // tokens[B][R][C] -> x; with a selection the LAST layer's column out-projection and FFN run on the selected rows only
+  // (x_sel), as in esm_trunk
+  int msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* sel_idx = nullptr, const int32_t* sel_row_map = nullptr,
+                int P = 0, int64_t n_sel = 0);
   int msa_gibbs_device(int32_t* d_tok, int B, int R, int C, const int32_t* d_idx, int n_iters, int P,
                        const pg_sample_params* sp, float* d_samp_logits, int32_t* d_samp_tok);
   // generate_single: B = 1; step s masks row mask_row and samples row target_row at d_step_idx[s][P_max]

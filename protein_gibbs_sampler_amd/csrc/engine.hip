@@ -388,7 +388,8 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
 // ------------------------------------------------------------------------------------------------
 // ESM-MSA-1b forward: tokens[B][R][C] -> x[B*R*C][d]
 // ------------------------------------------------------------------------------------------------
-int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C) {
+int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* sel_idx, const int32_t* sel_row_map, int P,
+                      int64_t n_sel) {
   const int d = cfg.d_model, f = cfg.d_ffn, H = cfg.n_heads;
   const int64_t M = (int64_t)B * R * C;
   const int64_t Mp = round_up64(M, kRowPad);
@@ -471,6 +472,25 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C) {
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_col.g, L.ln_col.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if ((rc = timed(PC_ATTN, [&] { return launch_attention_seq_bf16(stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col); }))) return rc;
+    if (sel_idx && l == cfg.n_layers - 1) {
+      // last layer: nothing but the selected rows is read again -> finish column out-projection and FFN on n_sel rows
+      const int64_t Np = round_up64(n_sel, kRowPad);
+      if ((rc = x_sel.ensure((size_t)Np * d * 4, stream)) || (rc = ctx_sel.ensure((size_t)Np * d * 2, stream)) ||
+          (rc = h_sel.ensure((size_t)Np * d * 2, stream)) || (rc = ffn_sel.ensure((size_t)Np * f * 2, stream))) return rc;
+      float* XS = x_sel.as<float>();
+      const int Ni = (int)Np;
+      rc = timed(PC_HEAD, [&] {
+        int r2 = launch_gather_rows(stream, X, XS, sel_idx, sel_row_map, P, C, n_sel, d * 4);
+        if (r2) return r2;
+        return launch_gather_rows(stream, CTX, ctx_sel.as<bf16_t>(), sel_idx, sel_row_map, P, C, n_sel, d * 2);
+      });
+      if (rc) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.col_out.w, L.col_out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln_ffn.g, L.ln_ffn.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID); }))) return rc;
+      break;
+    }
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.col_out.w, L.col_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
     // feed forward
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_ffn.g, L.ln_ffn.b, Hh, M, d, eps); }))) return rc;
@@ -502,10 +522,12 @@ int Engine::msa_gibbs_device(int32_t* d_tok, int B, int R, int C, const int32_t*
     const int32_t* idx_it = d_idx_ + (size_t)it * n_draws;
     if (sp->mask && P > 0)
       if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, C, idx_it, nullptr, n_sel_rows, P, sp->mask_idx); }))) return rc;
-    if ((rc = msa_trunk(d_tok, B, R, C))) return rc;
+    static const int prune = [] { const char* e = getenv("PGIBBS_PRUNE_LAST"); return e ? atoi(e) : 1; }();
+    const bool pruned = prune && !strict() && P > 0 && n_draws * 2 < n_sel_rows * C;
+    if ((rc = pruned ? msa_trunk(d_tok, B, R, C, idx_it, nullptr, P, n_draws) : msa_trunk(d_tok, B, R, C))) return rc;
     if (P == 0) continue;
     float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)it * n_draws * V : logits.as<float>();
-    if ((rc = head(idx_it, nullptr, P, C, n_draws, lg))) return rc;
+    if ((rc = pruned ? head(nullptr, nullptr, 1, 1, n_draws, lg, x_sel.as<float>()) : head(idx_it, nullptr, P, C, n_draws, lg))) return rc;
     int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)it * n_draws : nullptr;
     if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, it, st); }))) return rc;
   }
@@ -533,10 +555,12 @@ int Engine::msa_single_device(int32_t* d_tok, int R, int C, int mask_row, int ta
     const int32_t* idx_s = d_step_idx + (size_t)s * P_max;
     if (P_max > 0)   // generate_single always masks (esm_msa_sampler.py:133), row -1 regardless of the target row
       if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, C, idx_s, d_mask_map, 1, P_max, sp->mask_idx); }))) return rc;
-    if ((rc = msa_trunk(d_tok, 1, R, C))) return rc;
+    static const int prune = [] { const char* e = getenv("PGIBBS_PRUNE_LAST"); return e ? atoi(e) : 1; }();
+    const bool pruned = prune && !strict() && P_max > 0 && (int64_t)P_max * 2 < (int64_t)R * C;
+    if ((rc = pruned ? msa_trunk(d_tok, 1, R, C, idx_s, d_tgt_map, P_max, P_max) : msa_trunk(d_tok, 1, R, C))) return rc;
     if (P_max == 0) continue;
     float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)s * P_max * V : logits.as<float>();
-    if ((rc = head(idx_s, d_tgt_map, P_max, C, P_max, lg))) return rc;
+    if ((rc = pruned ? head(nullptr, nullptr, 1, 1, P_max, lg, x_sel.as<float>()) : head(idx_s, d_tgt_map, P_max, C, P_max, lg))) return rc;
     int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)s * P_max : nullptr;
     p.burnin = step_sample_flag_host[s] ? 0x7fffffff : 0;   // sample=(pass_num < burn_in), esm_msa_sampler.py:143
     if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg, V, 1, idx_s, d_tgt_map, 1, P_max, &p, s, st); }))) return rc;

@@ -8,6 +8,8 @@
 // r = 0..R-1 and accumulates the S^T blocks of the wave's 16 queries in registers with v_mfma_f32_16x16x32_bf16
 // (the same lane-local layout as attention.hip: a lane holds one query's scores for 4 keys of every 16-key block),
 // then one exact softmax; pass 2 streams V_r^T through LDS and emits ctx for every row with the same P fragments.
+// Row r+1's tile is fetched into registers while row r's MFMAs run, and the query chunks of one (msa, head) are
+// placed on one XCD so the re-streamed tiles hit its L2.
 #include "kernels.h"
 
 namespace pg {
@@ -18,15 +20,31 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <int MAXKB>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int R, int C, int H, int ld_qkv, int ld_ctx, int k_off,
-    int v_off, float scale, int n_qblk) {
+    int v_off, float scale, int n_qblk, int n_bh) {
   constexpr int VT_LD = MAXKB * 16 + 8;
-  constexpr int tpad = MAXKB * 16;
+  constexpr int tpad = MAXKB * 16, hpad = tpad / 2;
+  constexpr int NIT = (tpad * 8 + 255) / 256;      // K items per thread: one uint4 = 8 d of one key
+  constexpr int NVP = (hpad * 8 + 255) / 256;      // V items per thread: two adjacent keys x 8 d
   __shared__ __attribute__((aligned(16))) char smem[MAXKB * 16 * 128 + 64 * VT_LD * 2];
   char* Ks = smem;
   bf16_t* Vt = (bf16_t*)(smem + MAXKB * 16 * 128);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qblk = blockIdx.x % n_qblk, bh = blockIdx.x / n_qblk;
+  // XCD-aware mapping (block b runs on XCD b % 8): the query chunks of one (msa, head) get consecutive slots of ONE
+  // XCD, so the K_r / V_r tiles they all stream are served by that XCD's L2 after the first touch.
+  int qblk, bh;
+  {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int full = (n_bh / 8) * 8;                 // (msa, head) pairs covered by the XCD-aligned part of the grid
+    if ((int)blockIdx.x < full * n_qblk) {
+      bh = (slot / n_qblk) * 8 + xcd;
+      qblk = slot % n_qblk;
+    } else {                                         // remainder: plain order
+      const int rest = blockIdx.x - full * n_qblk;
+      bh = full + rest / n_qblk;
+      qblk = rest % n_qblk;
+    }
+  }
   const int b = bh / H, h = bh % H;
   const bf16_t* base = qkv + (size_t)b * R * C * ld_qkv + h * 64;   // row (r*C + i)
   const int fr = lane & 15, fq = lane >> 4;
@@ -39,18 +57,29 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
 #pragma unroll
   for (int kb = 0; kb < MAXKB; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- pass 1: scores summed over rows ------------------------------------------------------
-  for (int r = 0; r < R; ++r) {
+  // ---- pass 1: scores summed over rows.  The K tile of row r+1 is fetched into registers while row r's MFMAs run.
+  uint4 kreg[NIT];
+  auto load_k = [&](int r) {
     const bf16_t* rb = base + (size_t)r * C * ld_qkv;
-    __syncthreads();
-    for (int i = tid; i < tpad * 8; i += 256) {
-      const int row = i >> 3, c = i & 7;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < C) v = *(const uint4*)(rb + (size_t)row * ld_qkv + k_off + c * 8);
-      *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256, row = i >> 3, c = i & 7;
+      kreg[it] = make_uint4(0, 0, 0, 0);
+      if (i < tpad * 8 && row < C) kreg[it] = *(const uint4*)(rb + (size_t)row * ld_qkv + k_off + c * 8);
+    }
+  };
+  load_k(0);
+  for (int r = 0; r < R; ++r) {
+    __syncthreads();                                  // previous tile fully consumed
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256, row = i >> 3, c = i & 7;
+      if (i < tpad * 8) *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
     }
     __syncthreads();
+    if (r + 1 < R) load_k(r + 1);                     // in flight during the MFMAs below
     if (active) {
+      const bf16_t* rb = base + (size_t)r * C * ld_qkv;
       bf16x8 qf[2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(rb + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
@@ -67,6 +96,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
   }
 
   // ---- softmax over keys ---------------------------------------------------------------------
+  constexpr float LOG2E = 1.44269504088896341f;
   float mx = -3.0e38f;
   int tl = C - fq * 4;
 #pragma unroll
@@ -80,12 +110,13 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
   }
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float mneg = -mx * LOG2E;
   float sum = 0.f;
 #pragma unroll
   for (int kb = 0; kb < MAXKB; ++kb) {
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
-      const float e = __expf(st[kb][r4] - mx);
+      const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r4], LOG2E, mneg));
       st[kb][r4] = e;
       sum += e;
     }
@@ -104,19 +135,37 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
     pf[c].u[3] = pack_bf16x2(hi[2] * inv, hi[3] * inv);
   }
 
-  // ---- pass 2: ctx[r] = P . V_r for every row ------------------------------------------------
-  for (int r = 0; r < R; ++r) {
+  // ---- pass 2: ctx[r] = P . V_r for every row (V_r^T tile prefetched the same way) ----------------
+  uint4 va[NVP], vb[NVP];
+  auto load_v = [&](int r) {
     const bf16_t* rb = base + (size_t)r * C * ld_qkv;
-    __syncthreads();
-    for (int i = tid; i < tpad * 8; i += 256) {
-      const int key = i % tpad, c = i / tpad;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (key < C) v = *(const uint4*)(rb + (size_t)key * ld_qkv + v_off + c * 8);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * VT_LD + key] = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+    for (int it = 0; it < NVP; ++it) {
+      const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
+      va[it] = make_uint4(0, 0, 0, 0);
+      vb[it] = make_uint4(0, 0, 0, 0);
+      if (i < hpad * 8) {
+        if (2 * kp < C) va[it] = *(const uint4*)(rb + (size_t)(2 * kp) * ld_qkv + v_off + cv * 8);
+        if (2 * kp + 1 < C) vb[it] = *(const uint4*)(rb + (size_t)(2 * kp + 1) * ld_qkv + v_off + cv * 8);
+      }
+    }
+  };
+  load_v(0);
+  for (int r = 0; r < R; ++r) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NVP; ++it) {
+      const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
+      if (i < hpad * 8) {
+        const uint32_t a[4] = {va[it].x, va[it].y, va[it].z, va[it].w}, bb[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
+        uint32_t* vt32 = (uint32_t*)Vt;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          vt32[((cv * 8 + e) * VT_LD) / 2 + kp] = ((a[e >> 1] >> ((e & 1) * 16)) & 0xffffu) | (((bb[e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
+      }
     }
     __syncthreads();
+    if (r + 1 < R) load_v(r + 1);
     if (active) {
       f32x4 o[4];
 #pragma unroll
@@ -156,7 +205,7 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
 #define PG_ROWATT(KB)                                                                                                  \
   else if (C <= KB * 16) {                                                                                             \
     hipLaunchKernelGGL(msa_row_attention_kernel<KB>, grid, block, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx, k_off, v_off, \
-                       scale, n_qblk);                                                                                 \
+                       scale, n_qblk, B * H);                                                                          \
   }
   if (false) {}
   PG_ROWATT(2) PG_ROWATT(4) PG_ROWATT(8) PG_ROWATT(12) PG_ROWATT(18) PG_ROWATT(24) PG_ROWATT(30) PG_ROWATT(36)
