@@ -454,7 +454,12 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_row.g, L.ln_row.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if (C <= 576) {
-      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale); }))) return rc;
+      float* part = nullptr;
+      if (B * H * ((C + 63) / 64) < 384 && R >= 8) {      // few workgroups: give the kernel scratch for its split-R mode
+        const size_t need = (size_t)B * H * 16 * C * 576 * 4;
+        if (need <= ((size_t)1 << 31) && !(rc = scores.ensure(need, stream))) part = scores.as<float>();
+      }
+      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0); }))) return rc;
     } else {
       // alignments wider than the MFMA row-attention kernel's register budget: fp32 scores through a scratch buffer
       if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * C * 4, stream)) ||

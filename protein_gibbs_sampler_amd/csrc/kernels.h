@@ -25,8 +25,10 @@ int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, 
 int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int64_t n_seq, int T, int H, int ld_qkv,
                               int ld_ctx, int k_off, int v_off, SeqLayout sl);
 // MSA tied row attention: one C x C map per (msa, head) from scores summed over the R rows
+// `partial` (optional fp32 scratch of partial_bytes) enables the split-R mode used when B*H is small
 int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
-                                  int ld_ctx, int k_off, int v_off, float scale);
+                                  int ld_ctx, int k_off, int v_off, float scale, float* partial = nullptr,
+                                  size_t partial_bytes = 0);
 
 int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,

@@ -20,7 +20,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <int MAXKB>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int R, int C, int H, int ld_qkv, int ld_ctx, int k_off,
-    int v_off, float scale, int n_qblk, int n_bh) {
+    int v_off, float scale, int n_qblk, int n_bh, int mode, int n_rc, float* __restrict__ partial) {
+  // mode 0: fused (both passes over all R rows).  Split-R (few (msa, head) pairs, e.g. generate_single with B = 1):
+  // mode 1: pass 1 over the row chunk rc only, partial S^T -> partial[bh][rc][query][key];
+  // mode 2: S = sum of the n_rc partial maps, softmax, pass 2 over the row chunk rc only.
   constexpr int VT_LD = MAXKB * 16 + 8;
   constexpr int tpad = MAXKB * 16, hpad = tpad / 2;
   constexpr int NIT = (tpad * 8 + 255) / 256;      // K items per thread: one uint4 = 8 d of one key
@@ -33,18 +36,24 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
   // XCD-aware mapping (block b runs on XCD b % 8): the query chunks of one (msa, head) get consecutive slots of ONE
   // XCD, so the K_r / V_r tiles they all stream are served by that XCD's L2 after the first touch.
   int qblk, bh;
+  const int per_rc = n_bh * n_qblk;
+  const int rc = blockIdx.x / per_rc;                // row chunk (0 in fused mode)
   {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bidx = blockIdx.x - rc * per_rc;
+    const int xcd = bidx & 7, slot = bidx >> 3;
     const int full = (n_bh / 8) * 8;                 // (msa, head) pairs covered by the XCD-aligned part of the grid
-    if ((int)blockIdx.x < full * n_qblk) {
+    if (bidx < full * n_qblk) {
       bh = (slot / n_qblk) * 8 + xcd;
       qblk = slot % n_qblk;
     } else {                                         // remainder: plain order
-      const int rest = blockIdx.x - full * n_qblk;
+      const int rest = bidx - full * n_qblk;
       bh = full + rest / n_qblk;
       qblk = rest % n_qblk;
     }
   }
+  const int rsz = (R + n_rc - 1) / n_rc;
+  const int r_lo = mode == 0 ? 0 : rc * rsz;
+  const int r_hi = mode == 0 ? R : ((rc + 1) * rsz < R ? (rc + 1) * rsz : R);
   const int b = bh / H, h = bh % H;
   const bf16_t* base = qkv + (size_t)b * R * C * ld_qkv + h * 64;   // row (r*C + i)
   const int fr = lane & 15, fq = lane >> 4;
@@ -68,8 +77,8 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
       if (i < tpad * 8 && row < C) kreg[it] = *(const uint4*)(rb + (size_t)row * ld_qkv + k_off + c * 8);
     }
   };
-  load_k(0);
-  for (int r = 0; r < R; ++r) {
+  if (mode != 2 && r_lo < r_hi) load_k(r_lo);
+  for (int r = r_lo; r < r_hi && mode != 2; ++r) {
     __syncthreads();                                  // previous tile fully consumed
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
       if (i < tpad * 8) *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
     }
     __syncthreads();
-    if (r + 1 < R) load_k(r + 1);                     // in flight during the MFMAs below
+    if (r + 1 < r_hi) load_k(r + 1);                  // in flight during the MFMAs below
     if (active) {
       const bf16_t* rb = base + (size_t)r * C * ld_qkv;
       bf16x8 qf[2];
@@ -95,6 +104,25 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
     }
   }
 
+  if (mode == 1) {          // partial score map of this row chunk: lane stores its 4 keys x MAXKB blocks for query q0+fr
+    if (active && q0 + fr < C) {
+      float* dst = partial + (((size_t)bh * n_rc + rc) * C + (q0 + fr)) * tpad + fq * 4;
+#pragma unroll
+      for (int kb = 0; kb < MAXKB; ++kb) *(float4*)(dst + kb * 16) = make_float4(st[kb][0], st[kb][1], st[kb][2], st[kb][3]);
+    }
+    return;
+  }
+  if (mode == 2 && active) {
+    const int qq = (q0 + fr < C) ? q0 + fr : C - 1;
+    for (int c2 = 0; c2 < n_rc; ++c2) {
+      const float* src = partial + (((size_t)bh * n_rc + c2) * C + qq) * tpad + fq * 4;
+#pragma unroll
+      for (int kb = 0; kb < MAXKB; ++kb) {
+        const float4 v = *(const float4*)(src + kb * 16);
+        st[kb][0] += v.x; st[kb][1] += v.y; st[kb][2] += v.z; st[kb][3] += v.w;
+      }
+    }
+  }
   // ---- softmax over keys ---------------------------------------------------------------------
   constexpr float LOG2E = 1.44269504088896341f;
   float mx = -3.0e38f;
@@ -150,8 +178,8 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
       }
     }
   };
-  load_v(0);
-  for (int r = 0; r < R; ++r) {
+  if (r_lo < r_hi) load_v(r_lo);
+  for (int r = r_lo; r < r_hi; ++r) {
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NVP; ++it) {
@@ -165,7 +193,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
       }
     }
     __syncthreads();
-    if (r + 1 < R) load_v(r + 1);
+    if (r + 1 < r_hi) load_v(r + 1);
     if (active) {
       f32x4 o[4];
 #pragma unroll
@@ -197,21 +225,37 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
 }
 
 int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
-                                  int ld_ctx, int k_off, int v_off, float scale) {
+                                  int ld_ctx, int k_off, int v_off, float scale, float* partial, size_t partial_bytes) {
   if (B == 0 || R == 0) return 0;
   if (C <= 0) return fail(1, "row attention: empty alignment");
-  const int n_qblk = (C + 63) / 64;
-  dim3 grid((unsigned)(B * H * n_qblk)), block(256);
-#define PG_ROWATT(KB)                                                                                                  \
-  else if (C <= KB * 16) {                                                                                             \
-    hipLaunchKernelGGL(msa_row_attention_kernel<KB>, grid, block, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx, k_off, v_off, \
-                       scale, n_qblk, B * H);                                                                          \
+  const int n_qblk = (C + 63) / 64, n_bh = B * H;
+  // split the row loop over workgroups when the (msa, head, query-chunk) grid alone cannot fill the chip
+  int n_rc = 1;
+  if (partial && n_bh * n_qblk < 384 && R >= 8) {
+    n_rc = (768 + n_bh * n_qblk - 1) / (n_bh * n_qblk);
+    if (n_rc > R / 4) n_rc = R / 4;
+    if (n_rc < 1) n_rc = 1;
+  }
+  dim3 block(256);
+#define PG_ROWATT(KB)                                                                                                   \
+  else if (C <= KB * 16) {                                                                                              \
+    if (n_rc > 1 && (size_t)n_bh * n_rc * C * (KB * 16) * 4 > partial_bytes) n_rc = 1;                                  \
+    if (n_rc == 1) {                                                                                                    \
+      hipLaunchKernelGGL(msa_row_attention_kernel<KB>, dim3((unsigned)(n_bh * n_qblk)), block, 0, s, qkv, ctx, R, C, H,  \
+                         ld_qkv, ld_ctx, k_off, v_off, scale, n_qblk, n_bh, 0, 1, nullptr);                             \
+    } else {                                                                                                            \
+      const dim3 grid((unsigned)(n_bh * n_qblk * n_rc));                                                                \
+      hipLaunchKernelGGL(msa_row_attention_kernel<KB>, grid, block, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx, k_off,      \
+                         v_off, scale, n_qblk, n_bh, 1, n_rc, partial);                                                 \
+      hipLaunchKernelGGL(msa_row_attention_kernel<KB>, grid, block, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx, k_off,      \
+                         v_off, scale, n_qblk, n_bh, 2, n_rc, partial);                                                 \
+    }                                                                                                                   \
   }
   if (false) {}
   PG_ROWATT(2) PG_ROWATT(4) PG_ROWATT(8) PG_ROWATT(12) PG_ROWATT(18) PG_ROWATT(24) PG_ROWATT(30) PG_ROWATT(36)
 #undef PG_ROWATT
   else {
-    return fail(5, "row attention: alignments wider than 575 columns are not supported yet");
+    return fail(5, "row attention: alignments wider than 575 columns take the fp32-scores path");
   }
   PG_HIP(hipGetLastError());
   return 0;

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 BF16_TOL = 0.15
 
 
-@pytest.mark.parametrize("B,R,C,H", [(2, 3, 20, 2), (1, 32, 257, 2), (2, 5, 70, 1), (1, 8, 130, 3), (1, 2, 300, 1)])
+@pytest.mark.parametrize("B,R,C,H", [(2, 3, 20, 2), (1, 32, 257, 2), (2, 5, 70, 1), (1, 8, 130, 3), (1, 2, 300, 1),
+                                     (1, 128, 513, 1), (1, 37, 100, 2), (40, 9, 65, 12)])   # split-R and fused grids
 def test_row_attention_kernel(B, R, C, H):
     rng = np.random.default_rng(C)
     d = H * 64
@@ -83,7 +84,7 @@ def test_msa_forward_logits_vs_oracle():
     sd = synthetic_msa_weights(ocfg, seed=4, std=0.08, embed_std=0.5, ln_jitter=0.1)
     m = _model(sd).model.to("cuda:0")
     rng = np.random.default_rng(1)
-    for (B, R, C) in [(2, 4, 21), (1, 7, 66), (3, 1, 10)]:
+    for (B, R, C) in [(2, 4, 21), (1, 7, 66), (3, 1, 10), (1, 16, 70)]:
         tok = rng.integers(4, 24, (B, R, C))
         tok[rng.random((B, R, C)) < 0.1] = 30
         tok[rng.random((B, R, C)) < 0.1] = 32
