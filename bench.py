@@ -209,9 +209,14 @@ def main():
         parts = {c: lm.prof_get(c) for c in ("gemm", "attention", "layernorm", "embed", "head", "sample")}
         lm.prof_enable(False)
         if rank == 0 and launches:
-            gf = gemm_flops_per_iter(cfg, B * T, 0) * n_prof      # the head GEMM is timed under "head"
+            # FLOPs the GEMM launches actually executed: every layer on all B*T rows, except that the last layer's
+            # out-proj / fc1 / fc2 run on the B*P sampled rows only (exact pruning); head GEMM timed under "head"
+            d_, f_, nl_ = cfg["d_model"], cfg["d_ffn"], cfg["n_layers"]
+            full = 2.0 * (4 * d_ * d_ + 2 * d_ * f_) * (B * T)
+            last = 2.0 * (3 * d_ * d_) * (B * T) + 2.0 * (d_ * d_ + 2 * d_ * f_) * (B * P)
+            gf = ((nl_ - 1) * full + last) * n_prof
             achieved = gf / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all %d launches/iteration)" % (launches // n_prof),
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (all %d launches/iteration)" % (launches // n_prof),
                                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_gemm_traffic(),
                                "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated), avg over the 4 per-layer GEMMs; "

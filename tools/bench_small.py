@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Config 1 (BASELINE.json configs[0]): ESM-1b, one chain, L=25, 20 iterations, P=2, top_k=1, burnin=10 -- latency-bound."""
+import os, sys, time, random, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from protein_gibbs_sampler_amd import esm_sampler, models, weights
+cfg = dict(weights.ESM1B_CONFIG)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    s = esm_sampler.ESM_sampler(models.ESM1b(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg), device="gpu")
+seed = "MEPAATGQEAEECAHSGRGEAWEEV"
+kw = dict(batch_size=1, num_iters=20, burnin=10, mask=True, in_order=False, num_positions_percent=10, top_k=1, show_progress_bar=False)
+random.seed(0); s.generate(1, seed, **kw)
+for B in (1, 8, 32):
+    kw["batch_size"] = B
+    s.generate(B, seed, **kw)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s.generate(B, seed, **kw)
+    dt = (time.perf_counter() - t0) / 3
+    print("B=%d: %.2f ms per generate() = %.3f ms/iteration, %.0f positions/s" % (B, dt * 1e3, dt * 1e3 / 20, B * 2 * 20 / dt))
