@@ -289,7 +289,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   bf16_t* CTX = ctx.as<bf16_t>();
   bf16_t* FFN = ffn.as<bf16_t>();
   const float eps = cfg.layer_norm_eps;
-  const int Mi = (int)Mp;
+  const int Mi = M <= 256 ? round_up((int)M, 16) : (int)Mp;  // <= 256 rows: weight-streaming skinny GEMM (buffers stay 256-padded)
 
   rc = timed(PC_EMBED, [&] {
     return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
@@ -307,7 +307,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       if ((rc = x_sel.ensure((size_t)Np * d * 4, stream)) || (rc = ctx_sel.ensure((size_t)Np * d * 2, stream)) ||
           (rc = h_sel.ensure((size_t)Np * d * 2, stream)) || (rc = ffn_sel.ensure((size_t)Np * f * 2, stream))) return rc;
       float* XS = x_sel.as<float>();
-      const int Ni = (int)Np;
+      const int Ni = n_sel <= 256 ? round_up((int)n_sel, 16) : (int)Np;
       rc = timed(PC_HEAD, [&] {
         int r2 = launch_gather_rows(stream, X, XS, sel_idx, nullptr, P, T, n_sel, d * 4);
         if (r2) return r2;
@@ -351,8 +351,8 @@ int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int wid
     int r = launch_gather_ln_bf16(stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
                                   sel_h.as<bf16_t>(), n_sel, d, eps);
     if (r) return r;
-    r = launch_gemm_bf16(stream, sel_h.as<bf16_t>(), head_dense.w, head_dense.b, sel_g.as<float>(), (int)Np, d, d, d, d, d,
-                         EPI_F32_GELU);
+    r = launch_gemm_bf16(stream, sel_h.as<bf16_t>(), head_dense.w, head_dense.b, sel_g.as<float>(),
+                         n_sel <= 256 ? round_up((int)n_sel, 16) : (int)Np, d, d, d, d, d, EPI_F32_GELU);
     if (r) return r;
     return launch_lm_tail(stream, sel_g.as<float>(), head_ln.g, head_ln.b, embed, head_bias, d_logits, n_sel, d, V, eps);
   });

@@ -427,6 +427,122 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM for M <= 256 token rows (BASELINE config 1: one chain of 27 tokens; small interactive jobs; LM-head GEMMs).
+// With so few rows the op is pure weight streaming (HBM roofline: 1.3 GB of bf16 weights per forward), and a 256x256
+// tile grid would put 5-20 workgroups on 256 CUs.  Here: one workgroup per 16 output features (N/16 = 80..320
+// workgroups), its 4 waves split K four ways; W fragments go global -> VGPR directly (each byte is used once, an LDS
+// round trip would be pure overhead), the tiny X operand comes from L2; partial sums meet in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias, void* __restrict__ out, int K,
+                                                              int ldx, int ldw, int ldo) {
+  __shared__ float red[NW - 1][MT][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kq = K / NW;                                 // this wave's K range: a multiple of 16 (NW=4) or 32 (NW=8)
+  const bf16_t* wp = W + (size_t)(n0 + fr) * ldw + wave * kq + fq * 8;
+  const bf16_t* xp = X + (size_t)fr * ldx + wave * kq + fq * 8;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  constexpr int U = MT <= 4 ? 4 : (MT <= 8 ? 2 : 1);     // MFMA k-steps per trip (all loads issued first; <= 64 fragment VGPRs)
+  for (; k + 32 * U <= kq; k += 32 * U) {
+    bf16x8 wf[U], xf[U][MT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      wf[u] = *(const bf16x8*)(wp + k + u * 32);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xf[u][t] = *(const bf16x8*)(xp + (size_t)t * 16 * ldx + k + u * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][t], acc[t], 0, 0, 0);
+  }
+  for (; k < kq; k += 32) {
+    if (k + 32 <= kq) {
+      const bf16x8 wf = *(const bf16x8*)(wp + k);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, *(const bf16x8*)(xp + (size_t)t * 16 * ldx + k), acc[t], 0, 0, 0);
+    } else {                                             // 16-wide tail of the wave's range: upper k-chunks are zero
+      bf16x8 wf, xz;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { wf[e] = (__bf16)0.f; xz[e] = (__bf16)0.f; }
+      if (fq < 2) wf = *(const bf16x8*)(wp + k);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        bf16x8 xf = xz;
+        if (fq < 2) xf = *(const bf16x8*)(xp + (size_t)t * 16 * ldx + k);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *(f32x4*)&red[wave - 1][t][lane][0] = acc[t];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  // lane holds D[n = n0 + fq*4 + r][m = t*16 + fr]
+  const float4 b4 = *(const float4*)(bias + n0 + fq * 4);
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    f32x4 v = acc[t];
+#pragma unroll
+    for (int w2 = 0; w2 < NW - 1; ++w2) {
+      const f32x4 o = *(const f32x4*)&red[w2][t][lane][0];
+      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    float v0 = v[0] + b4.x, v1 = v[1] + b4.y, v2 = v[2] + b4.z, v3 = v[3] + b4.w;
+    if (EPI == EPI_BF16_GELU || EPI == EPI_F32_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+    const size_t o = (size_t)(t * 16 + fr) * ldo + n0 + fq * 4;
+    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+      uint2 p;
+      p.x = pack_bf16x2(v0, v1);
+      p.y = pack_bf16x2(v2, v3);
+      *(uint2*)((bf16_t*)out + o) = p;
+    } else if (EPI == EPI_F32_RESID) {
+      float4* dst = (float4*)((float*)out + o);
+      float4 r = *dst;
+      r.x += v0; r.y += v1; r.z += v2; r.w += v3;
+      *dst = r;
+    } else {
+      *(float4*)((float*)out + o) = make_float4(v0, v1, v2, v3);
+    }
+  }
+}
+
+template <int MT>
+static int launch_skinny_mt(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int N, int K, int ldx,
+                            int ldw, int ldo, int epi) {
+  // 8 waves per workgroup (K split 8 ways: twice the loads in flight per CU) whenever each wave still gets whole
+  // 32-wide k-steps and the m-tile count keeps the register footprint small
+  const bool w8 = (K % 256 == 0) && MT <= 4;
+  dim3 grid(N / 16), block(w8 ? 512 : 256);
+#define PG_GEMM_CASE(E)                                                                                              \
+  case E:                                                                                                            \
+    if (w8) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, E, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo); \
+    else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, E, 4>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo);    \
+    break;
+  switch (epi) {
+    PG_GEMM_CASE(EPI_BF16)
+    PG_GEMM_CASE(EPI_BF16_GELU)
+    PG_GEMM_CASE(EPI_F32_RESID)
+    PG_GEMM_CASE(EPI_F32)
+    PG_GEMM_CASE(EPI_F32_GELU)
+    default:
+      return fail(1, "gemm: bad epilogue");
+  }
+#undef PG_GEMM_CASE
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                       int K, int ldx, int ldw, int ldo, int epi) {
@@ -459,6 +575,15 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant) {
+  if (M >= 16 && M <= 256 && M % 16 == 0 && N % 16 == 0 && K % 64 == 0 && variant != 1) {
+    // rows beyond M inside the last m-tile group are read/written too: callers pad buffers to 256 rows
+    const int mt = M / 16;
+    if (mt <= 1) return launch_skinny_mt<1>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
+    if (mt <= 2) return launch_skinny_mt<2>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
+    if (mt <= 4) return launch_skinny_mt<4>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
+    if (mt <= 8) return launch_skinny_mt<8>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
+    return launch_skinny_mt<16>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
+  }
   if (M % 128 || N % 128 || K % 64) return fail(1, "gemm: M,N must be multiples of 128 and K of 64");
   if (M % 256 == 0 && N % 256 == 0 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
   // (Peeling the 1-3 % full last round of tiles into a trailing 128x128 launch was measured: no gain -- blocks do not

@@ -22,7 +22,10 @@ def _gelu(x):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(300, 256, 128, 0), (70, 128, 64, 0), (256, 384, 256, 1), (513, 1280, 1280, 0),
-                                       (1000, 512, 5120, 1)])
+                                       (1000, 512, 5120, 1),
+                                       # skinny (M <= 64) weight-streaming kernel
+                                       (27, 1280, 1280, 0), (1, 128, 64, 0), (16, 3840, 1280, 1), (64, 1280, 5120, 0), (33, 256, 192, 1),
+                                       (100, 1280, 1280, 0), (216, 5120, 1280, 1), (256, 768, 3072, 0), (129, 128, 64, 0)])
 def test_gemm_bf16(M, N, K, epi):
     rng = np.random.default_rng(M + N + K)
     x = rng.standard_normal((M, K), dtype=np.float32)
