@@ -207,9 +207,11 @@ __global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __rest
 // dst[r] = src[row_of(r) * width + idx[r]] for 16-byte chunks; idx < 0 -> row 0 (value never read back)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
                                                          const int32_t* __restrict__ idx, const int32_t* __restrict__ row_map,
-                                                         int P, int width, int64_t n_sel, int chunks) {
+                                                         int P, int width, int64_t n_sel, int chunks,
+                                                         const int32_t* __restrict__ d_iter) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_sel) return;
+  if (d_iter) idx += (size_t)(*d_iter) * n_sel;
   int pos = idx[r];
   pos = pos < 0 ? 0 : (pos & 0x3fffffff);
   const int64_t s = r / P;
@@ -335,11 +337,11 @@ int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, con
 }
 
 int launch_gather_rows(hipStream_t s, const void* src, void* dst, const int32_t* idx, const int32_t* row_map, int P, int width,
-                       int64_t n_sel, int row_bytes) {
+                       int64_t n_sel, int row_bytes, const int32_t* d_iter) {
   if (n_sel == 0) return 0;
   if (row_bytes % 16) return fail(1, "gather: rows must be multiples of 16 bytes");
   hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_grid(n_sel)), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, idx, row_map, P,
-                     width, n_sel, row_bytes / 16);
+                     width, n_sel, row_bytes / 16, d_iter);
   PG_HIP(hipGetLastError());
   return 0;
 }

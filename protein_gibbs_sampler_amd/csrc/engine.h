@@ -66,6 +66,11 @@ struct Engine {
   DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
   // strict precision mode (PG_PREC_FP32): lo halves of the split-bf16 operands, fp32 GEMM outputs, row-attention scores
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
+  // launch-bound (small) Gibbs loops: one iteration captured as a hipGraph and replayed; the iteration number lives in
+  // d_iter on the device, so the same graph serves every iteration
+  DevBuf d_iter;
+  hipGraphExec_t graph_exec = nullptr;
+  std::vector<uint8_t> graph_key;
   DevBuf h_lo, ctx_lo, ffn_lo, ffn_f32, sel_h_lo, scores, zero_bias;
   bool strict() const { return precision == PG_PREC_FP32; }
   // out[Mp][N] fp32 (=|+=) X.W^T + b with X = xh + xl, W = w + w_lo:  xh.w + xh.w_lo + xl.w  (three MFMA GEMMs)
@@ -79,7 +84,8 @@ struct Engine {
   // tokens -> x (before ln_after).  With a selection (sel_idx != nullptr, bf16 mode) the LAST layer's out-proj, LN2 and
   // FFN run only on the selected rows and x_sel [n_sel][d] holds their residual stream (exact: nothing else reads
   // the last layer's output); head_compact() then consumes x_sel.
-  int esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx = nullptr, int P = 0, int64_t n_sel = 0);
+  int esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx = nullptr, int P = 0, int64_t n_sel = 0,
+                const int32_t* d_iter = nullptr);
   int head(const int32_t* d_idx, const int32_t* d_row_map, int P, int width, int64_t n_sel, float* d_logits,
            const float* x_src = nullptr);
   int esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp,

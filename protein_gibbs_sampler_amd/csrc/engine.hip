@@ -23,8 +23,12 @@ int fail(int code, const std::string& msg) {
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
 // ------------------------------------------------------------------------------------------------
+// bumped whenever any workspace buffer is (re)allocated: a captured graph holds raw pointers and must be re-captured
+static uint64_t g_alloc_epoch = 0;
+
 int DevBuf::ensure(size_t need, hipStream_t s) {
   if (need <= bytes) return 0;
+  ++g_alloc_epoch;
   size_t cap = need + need / 8 + 4096;
   void* np = nullptr;
   PG_HIP(hipMalloc(&np, cap));
@@ -88,9 +92,10 @@ Engine::~Engine() {
   if (device >= 0) (void)hipSetDevice(device);
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
-                    &d_rowmap, &scratch, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &h_lo, &ctx_lo, &ffn_lo, &ffn_f32, &sel_h_lo, &scores, &zero_bias};
+                    &d_rowmap, &scratch, &d_iter, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &h_lo, &ctx_lo, &ffn_lo, &ffn_f32, &sel_h_lo, &scores, &zero_bias};
   for (DevBuf* b : bufs) b->release();
   prof.destroy();
+  if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
   if (own_stream) (void)hipStreamDestroy(own_stream);
 }
 
@@ -242,7 +247,7 @@ int Engine::dense3(const bf16_t* xh, const bf16_t* xl, const DenseW& W, float* o
 // ------------------------------------------------------------------------------------------------
 // ESM-1b forward: tokens[B][T] -> x[B*T][d] (residual stream before emb_layer_norm_after)
 // ------------------------------------------------------------------------------------------------
-int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx, int P, int64_t n_sel) {
+int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx, int P, int64_t n_sel, const int32_t* d_iter_) {
   const int d = cfg.d_model, f = cfg.d_ffn;
   const int64_t M = (int64_t)B * T;
   const int64_t Mp = round_up64(M, kRowPad);
@@ -309,9 +314,9 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       float* XS = x_sel.as<float>();
       const int Ni = n_sel <= 256 ? round_up((int)n_sel, 16) : (int)Np;
       rc = timed(PC_HEAD, [&] {
-        int r2 = launch_gather_rows(stream, X, XS, sel_idx, nullptr, P, T, n_sel, d * 4);
+        int r2 = launch_gather_rows(stream, X, XS, sel_idx, nullptr, P, T, n_sel, d * 4, d_iter_);
         if (r2) return r2;
-        return launch_gather_rows(stream, CTX, ctx_sel.as<bf16_t>(), sel_idx, nullptr, P, T, n_sel, d * 2);
+        return launch_gather_rows(stream, CTX, ctx_sel.as<bf16_t>(), sel_idx, nullptr, P, T, n_sel, d * 2, d_iter_);
       });
       if (rc) return rc;
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.out.w, L.out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
@@ -369,19 +374,61 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
   const int64_t n_draws = (int64_t)B * P;
   int rc;
   if (!d_samp_logits_ && (rc = logits.ensure((size_t)(n_draws > 0 ? n_draws : 1) * V * 4, stream))) return rc;
-  for (int it = 0; it < n_iters; ++it) {
-    const int32_t* idx_it = d_idx_ + (size_t)it * n_draws;
+  static const int prune = [] { const char* e = getenv("PGIBBS_PRUNE_LAST"); return e ? atoi(e) : 1; }();
+  static const int use_graph = [] { const char* e = getenv("PGIBBS_GRAPH"); return e ? atoi(e) : 1; }();
+  const bool pruned = prune && !strict() && P > 0 && n_draws * 2 < (int64_t)B * T;
+
+  // one Gibbs iteration; with dit != nullptr every iteration-dependent quantity is derived on the device from *dit
+  auto iteration = [&](int it, const int32_t* dit) -> int {
+    const int32_t* idx_it = dit ? d_idx_ : d_idx_ + (size_t)it * n_draws;
+    int r;
     if (sp->mask && P > 0)
-      if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, T, idx_it, nullptr, n_sel_rows, P, sp->mask_idx); }))) return rc;
-    static const int prune = [] { const char* e = getenv("PGIBBS_PRUNE_LAST"); return e ? atoi(e) : 1; }();
-    const bool pruned = prune && !strict() && P > 0 && n_draws * 2 < (int64_t)B * T;
-    if ((rc = pruned ? esm_trunk(d_tok, B, T, idx_it, P, n_draws) : esm_trunk(d_tok, B, T))) return rc;
-    if (P == 0) continue;
+      if ((r = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, T, idx_it, nullptr, n_sel_rows, P, sp->mask_idx, dit); }))) return r;
+    if ((r = pruned ? esm_trunk(d_tok, B, T, idx_it, P, n_draws, dit) : esm_trunk(d_tok, B, T))) return r;
+    if (P == 0) return PG_OK;
     float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)it * n_draws * V : logits.as<float>();
-    if ((rc = pruned ? head(nullptr, nullptr, 1, 1, n_draws, lg, x_sel.as<float>()) : head(idx_it, nullptr, P, T, n_draws, lg))) return rc;
+    if ((r = pruned ? head(nullptr, nullptr, 1, 1, n_draws, lg, x_sel.as<float>()) : head(idx_it, nullptr, P, T, n_draws, lg))) return r;
     int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)it * n_draws : nullptr;
-    if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, T, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, it, st); }))) return rc;
+    return timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, T, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, dit ? 0 : it, st, dit); });
+  };
+
+  // Launch-bound regime (few tokens: ~270 launches of a few microseconds each): capture ONE iteration as a hipGraph and
+  // replay it.  Needs the pruned path (no per-iteration pointers besides the idx table), no per-iteration outputs, no
+  // event profiling.  Iteration 0 runs eagerly (it sizes every workspace buffer: no allocation inside the capture).
+  const bool graphable = use_graph && pruned && !prof.on && !d_samp_logits_ && !d_samp_tok_ && n_iters >= 3 &&
+                         (int64_t)B * T <= 4096;
+  if (!graphable) {
+    for (int it = 0; it < n_iters; ++it)
+      if ((rc = iteration(it, nullptr))) return rc;
+    return PG_OK;
   }
+  if ((rc = d_iter.ensure(4, stream))) return rc;
+  if ((rc = iteration(0, nullptr))) return rc;
+  std::vector<uint8_t> key(sizeof(pg_sample_params) + 7 * sizeof(int64_t));
+  {
+    pg_sample_params k = *sp;          // every field is baked into the captured kernel arguments (incl. iter_base)
+    memcpy(key.data(), &k, sizeof(k));
+    const int64_t dims[7] = {(int64_t)(uintptr_t)d_tok, (int64_t)(uintptr_t)d_idx_, B, T, P, (int64_t)(uintptr_t)stream,
+                             (int64_t)g_alloc_epoch};
+    memcpy(key.data() + sizeof(k), dims, sizeof(dims));
+  }
+  if (!graph_exec || key != graph_key) {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    PG_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    rc = iteration(0, d_iter.as<int32_t>());
+    if (!rc) rc = launch_iter_counter(stream, d_iter.as<int32_t>(), false, 0);
+    hipError_t ce = hipStreamEndCapture(stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return fail(PG_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    ce = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ce != hipSuccess) { graph_exec = nullptr; return fail(PG_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); }
+    graph_key = key;
+  }
+  // replay iterations 1 .. n_iters-1: the counter selects the idx slice, the Philox iteration word and the burn-in flag
+  if ((rc = launch_iter_counter(stream, d_iter.as<int32_t>(), true, 1))) return rc;
+  for (int it = 1; it < n_iters; ++it) PG_HIP(hipGraphLaunch(graph_exec, stream));
   return PG_OK;
 }
 

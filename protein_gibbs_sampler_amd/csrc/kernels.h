@@ -49,8 +49,10 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx_hi, bf16_t
 // strict tied row attention; `scores` is an fp32 scratch of B*H*C*C floats
 int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx_hi, bf16_t* ctx_lo, int B, int R,
                                  int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale);
+// d_iter (optional): device-side iteration counter; idx is then the base of a [n_iters][...] table (hipGraph replay)
 int launch_gather_rows(hipStream_t s, const void* src, void* dst, const int32_t* idx, const int32_t* row_map, int P, int width,
-                       int64_t n_sel, int row_bytes);
+                       int64_t n_sel, int row_bytes, const int32_t* d_iter = nullptr);
+int launch_iter_counter(hipStream_t st, int32_t* d_iter, bool set, int value);
 int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const float* beta, const float* embed,
                    const float* out_bias, float* logits, int64_t n, int d, int V, float eps);
 int launch_f32_to_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t n, float scale);
@@ -60,9 +62,9 @@ int launch_scale_f32(hipStream_t s, float* p, int64_t n, float scale);
 int launch_logprob_gather(hipStream_t st, const float* logits, int V, int compact, int width, const int32_t* idx,
                           const int32_t* row_map, const int32_t* targets, int64_t n_sel, int P, float* out);
 int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
-                        int64_t n_sel, int P, int mask_idx);
+                        int64_t n_sel, int P, int mask_idx, const int32_t* d_iter = nullptr);
 int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const float* logits, int V, int compact,
                             const int32_t* idx, const int32_t* row_map, int64_t n_sel, int P, const pg_sample_params* p,
-                            int iteration, int32_t* sampled_tokens);
+                            int iteration, int32_t* sampled_tokens, const int32_t* d_iter = nullptr);
 
 }  // namespace pg

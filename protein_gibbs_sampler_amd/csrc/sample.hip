@@ -62,6 +62,7 @@ struct SampleArgs {
   int32_t n_valid;
   int32_t valid_idx[32];
   uint32_t seed_lo, seed_hi, stream, row_id_base, iter;
+  int32_t burnin;             // used with a device-side iteration counter: sample = (it < burnin)
 };
 
 // logits addressing: compact [n_sel*P][V] (engine path: LM head evaluated only at the sampled rows),
@@ -70,9 +71,16 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
                                                               const float* __restrict__ logits, int V, int compact,
                                                               const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ row_map, int64_t n_sel, int P,
-                                                              SampleArgs a, int32_t* __restrict__ sampled_tokens) {
+                                                              SampleArgs a, int32_t* __restrict__ sampled_tokens,
+                                                              const int32_t* __restrict__ d_iter) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_sel * P) return;
+  if (d_iter) {               // graph replay: the iteration number lives on the device (one captured graph, replayed)
+    const int it = *d_iter;
+    idx += (size_t)it * n_sel * P;
+    a.iter += (uint32_t)it;
+    a.sample = it < a.burnin ? 1 : 0;
+  }
   const int64_t s = i / P;
   const int slot = (int)(i - s * P);
   const int raw = idx[i];
@@ -144,9 +152,10 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
 __global__ __launch_bounds__(256) void mask_scatter_kernel(int32_t* __restrict__ tokens, int width,
                                                           const int32_t* __restrict__ idx,
                                                           const int32_t* __restrict__ row_map, int64_t n_sel, int P,
-                                                          int mask_idx) {
+                                                          int mask_idx, const int32_t* __restrict__ d_iter) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_sel * P) return;
+  if (d_iter) idx += (size_t)(*d_iter) * n_sel * P;
   const int raw = idx[i];
   if (raw < 0) return;
   const int64_t s = i / P;
@@ -186,19 +195,28 @@ int launch_logprob_gather(hipStream_t st, const float* logits, int V, int compac
   return 0;
 }
 
+__global__ void iter_counter_kernel(int32_t* d_iter, int set, int value) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *d_iter = set ? value : *d_iter + 1;
+}
+int launch_iter_counter(hipStream_t st, int32_t* d_iter, bool set, int value) {
+  hipLaunchKernelGGL(iter_counter_kernel, dim3(1), dim3(64), 0, st, d_iter, set ? 1 : 0, value);
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
-                        int64_t n_sel, int P, int mask_idx) {
+                        int64_t n_sel, int P, int mask_idx, const int32_t* d_iter) {
   const int64_t n = n_sel * P;
   if (n == 0) return 0;
   hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, width, idx, row_map,
-                     n_sel, P, mask_idx);
+                     n_sel, P, mask_idx, d_iter);
   PG_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const float* logits, int V, int compact,
                             const int32_t* idx, const int32_t* row_map, int64_t n_sel, int P, const pg_sample_params* p,
-                            int iteration, int32_t* sampled_tokens) {
+                            int iteration, int32_t* sampled_tokens, const int32_t* d_iter) {
   if (p->n_valid < 1 || p->n_valid > 32) return fail(1, "sample: n_valid must be in 1..32");
   for (int j = 0; j < p->n_valid; ++j)
     if (p->valid_idx[j] < 0 || p->valid_idx[j] >= V) return fail(1, "sample: valid_idx out of range");
@@ -216,8 +234,9 @@ int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const fl
   a.stream = p->rng_stream;
   a.row_id_base = p->row_id_base;
   a.iter = (uint32_t)(p->iter_base + iteration);
+  a.burnin = p->burnin;
   hipLaunchKernelGGL(sample_writeback_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, width, logits, V,
-                     compact, idx, row_map, n_sel, P, a, sampled_tokens);
+                     compact, idx, row_map, n_sel, P, a, sampled_tokens, d_iter);
   PG_HIP(hipGetLastError());
   return 0;
 }
