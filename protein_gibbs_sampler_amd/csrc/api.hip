@@ -381,7 +381,9 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
   PG_HIP(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
   if ((rc = launch_f32_to_bf16(nullptr, dx, bx, (int64_t)Mp * K, 1.f))) return rc;
   if ((rc = launch_f32_to_bf16(nullptr, dw, bw, (int64_t)N * K, 1.f))) return rc;
-  if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N, epi ? EPI_F32_GELU : EPI_F32))) return rc;
+  if (epi == 2) PG_HIP(hipMemcpy(dout, out, (size_t)M * N * 4, hipMemcpyHostToDevice));     // residual variant: out += x w^T + b
+  if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
+                             epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32)))) return rc;
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
   return PG_OK;

@@ -43,6 +43,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x + 0.5f * fabsf(x) * e;                 // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
 }
 
+// GELU for bf16 outputs (fc1 of the bf16 path): 0.5 x (1 + erf(x/sqrt2)) = relu(x) - |x| Phi(-|x|), with
+// log2 Phi(-t) fitted by a degree-5 polynomial on t >= 0 (max abs error of the GELU 3.2e-6 -- three orders below the
+// bf16 rounding of the result -- and a small RELATIVE error in the negative tail; the leading coefficient is negative,
+// so the power underflows to 0 for large t).  5 FMA + 1 v_exp + 2 ops; the fc1 epilogue is VALU-bound, and this is
+// half the instruction count of gelu_erf (which the fp32 outputs of the strict path keep).
+__device__ __forceinline__ float gelu_bf16out(float x) {
+  const float t = fabsf(x);
+  float p = -4.074793151e-04f;
+  p = fmaf(p, t, 6.563348950e-03f);
+  p = fmaf(p, t, -5.032995553e-02f);
+  p = fmaf(p, t, -4.618885100e-01f);
+  p = fmaf(p, t, -1.149779793e+00f);
+  p = fmaf(p, t, -1.000206717e+00f);
+  return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
+}
+
 // Stage ROWS x 64 bf16 (128 B per row) into LDS.  One wave-instruction = 8 rows = 1 KiB, written
 // lane-linearly; lane l covers row (l>>3), LDS chunk (l&7), which receives global chunk (l&7)^(row&7).
 template <int ROWS, int NW>
@@ -132,9 +148,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
     for (int j = 0; j < TM; ++j) {
       const int m = m0 + wm * WM + j * 16 + fr;
       float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-      if (EPI == EPI_BF16_GELU || EPI == EPI_F32_GELU) {
-        v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
-      }
+      if (EPI == EPI_F32_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+      if (EPI == EPI_BF16_GELU) { v0 = gelu_bf16out(v0); v1 = gelu_bf16out(v1); v2 = gelu_bf16out(v2); v3 = gelu_bf16out(v3); }
       if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
         uint2 p;
         p.x = pack_bf16x2(v0, v1);
@@ -162,12 +177,121 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
 // 64 lanes x 16 B = 1 KiB of contiguous output (bf16: two 512-B rows; fp32: one 1-KB row; the fp32 residual
 // read-modify-write uses the same row-shaped accesses, 16 loads in flight per lane).
 // ------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t row_rsrc(void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ f32x4 buf_load_f32x4(rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+// Stores keep the row step in the VGPR offset: with an SGPR soffset the compiler's hazard recogniser assumes a 128-bit
+// store's data registers may be overwritten by the very next VALU instruction, and on gfx950 that corrupted the last
+// dword of the stored row (seen as wrong .w components in lanes 12-15 of each 16) -- with soffset = 0 it pads the hazard.
+__device__ __forceinline__ void buf_store_f32x4(f32x4 v, rsrc_t rs, int voff, int row_off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, 0);
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int wm, int wn, int wave, int lane, int m0,
                                              int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo) {
   const int fr = lane & 15, fq = lane >> 4;
   __syncthreads();
-  if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+  // fp32-staged epilogues (fp32 outputs, and fc1's bf16+GELU).  Two phases; in phase p EVERY wave stages its accumulator
+  // columns j = 4p..4p+3 (64 token rows per wave group -> 128 staged rows x 1 KiB = all of LDS), then wave w owns the 16
+  // staged rows w*16.. = token rows m0 + (w>>2)*128 + (4p + (w&3))*16 + it and moves them out as whole 1-KiB rows.
+  // Residual variant: the 16 row loads of a phase (64 VGPRs) are issued BEFORE that phase's LDS staging, and phase 1's
+  // loads before phase 0's stores, so a tile exposes about one memory latency instead of four.
+  if (EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_F32_RESID) {
+    auto stage = [&](int p) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 b4 = *(const float4*)(bias + n0 + wn * 64 + i * 16 + fq * 4);
+        const int c = wn * 16 + i * 4 + fq;                       // 16-B chunk of the 1-KB row
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int sr = wm * 64 + jj * 16 + fr;
+          const f32x4 a = acc[i][p * 4 + jj];
+          float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+          if (EPI == EPI_F32_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+          *(float4*)(smem + sr * 1024 + ((c ^ (sr & 63)) << 4)) = v;
+        }
+      }
+    };
+    // first token row of this wave's 16 staged rows in phase p (wave-uniform)
+    auto grow = [&](int p) { return m0 + (wave >> 2) * 128 + (p * 4 + (wave & 3)) * 16; };
+    if (EPI == EPI_BF16_GELU) {
+      // fc1: the erf-GELU (about 20 VALU ops per element) runs in the LDS -> global phase, where it overlaps with the
+      // store-issue stalls of the other wave on the SIMD.  The value rounded to bf16 is the same fp32 the direct
+      // epilogue would produce.
+      const int c8 = lane & 31;                                   // 8 consecutive features = fp32 chunks 2*c8, 2*c8+1
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        if (p) __syncthreads();
+        stage(p);
+        __syncthreads();
+        bf16_t* ob = (bf16_t*)out + (size_t)grow(p) * ldo + n0;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int r2 = it * 2 + (lane >> 5), sr = wave * 16 + r2;
+          const float4 a = *(const float4*)(smem + sr * 1024 + (((2 * c8) ^ (sr & 63)) << 4));
+          const float4 b = *(const float4*)(smem + sr * 1024 + (((2 * c8 + 1) ^ (sr & 63)) << 4));
+          uint4 v;
+          v.x = pack_bf16x2(gelu_bf16out(a.x), gelu_bf16out(a.y));
+          v.y = pack_bf16x2(gelu_bf16out(a.z), gelu_bf16out(a.w));
+          v.z = pack_bf16x2(gelu_bf16out(b.x), gelu_bf16out(b.y));
+          v.w = pack_bf16x2(gelu_bf16out(b.z), gelu_bf16out(b.w));
+          *(uint4*)(ob + (size_t)r2 * ldo + c8 * 8) = v;
+        }
+      }
+      return;
+    }
+    if (EPI == EPI_F32_RESID) {
+      // Row-shaped accesses as buffer ops: wave-uniform row base in the resource, the row step in an SGPR offset, one
+      // VGPR (lane*16) for all 64 accesses -- 64-bit per-row VGPR addresses would not leave room for 32 rows in flight.
+      const rsrc_t rs0 = row_rsrc((float*)out + (size_t)grow(0) * ldo + n0);
+      const rsrc_t rs1 = row_rsrc((float*)out + (size_t)grow(1) * ldo + n0);
+      const int rstep = ldo * 4, voff = lane * 16;
+      f32x4 r0[16], r1[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) r0[it] = buf_load_f32x4(rs0, voff, it * rstep);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(0);
+      __builtin_amdgcn_sched_barrier(0);          // r1 must not be hoisted above the staging (register budget)
+#pragma unroll
+      for (int it = 0; it < 16; ++it) r1[it] = buf_load_f32x4(rs1, voff, it * rstep);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int sr = wave * 16 + it;
+        const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
+        buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep);
+      }
+      __syncthreads();
+      stage(1);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int sr = wave * 16 + it;
+        const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
+        buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep);
+      }
+      return;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p) __syncthreads();
+      stage(p);
+      __syncthreads();
+      float* ob = (float*)out + (size_t)grow(p) * ldo + n0;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int sr = wave * 16 + it;
+        *(float4*)(ob + (size_t)it * ldo + lane * 4) = *(const float4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
+      }
+    }
+    return;
+  }
+  {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 b4 = *(const float4*)(bias + n0 + wn * 64 + i * 16 + fq * 4);
@@ -175,8 +299,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int row = wm * 128 + j * 16 + fr;
-        float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-        if (EPI == EPI_BF16_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+        const float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
         uint2 p;
         p.x = pack_bf16x2(v0, v1);
         p.y = pack_bf16x2(v2, v3);
@@ -190,48 +313,6 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       const int row = (wave * 16 + it) * 2 + (lane >> 5);
       const uint4 v = *(const uint4*)(smem + row * 512 + ((c ^ (row & 31)) << 4));
       *(uint4*)((bf16_t*)out + (size_t)(m0 + row) * ldo + n0 + c * 8) = v;
-    }
-  } else {
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      if (ph) __syncthreads();
-      if (wm == ph) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 b4 = *(const float4*)(bias + n0 + wn * 64 + i * 16 + fq * 4);
-          const int c = wn * 16 + i * 4 + fq;                     // 16-B chunk of the 1-KB row
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int row = j * 16 + fr;
-            float4 v = make_float4(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w);
-            if (EPI == EPI_F32_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-            *(float4*)(smem + row * 1024 + ((c ^ (row & 63)) << 4)) = v;
-          }
-        }
-      }
-      __syncthreads();
-      float* obase = (float*)out + (size_t)(m0 + ph * 128 + wave * 16) * ldo + n0 + lane * 4;
-      if (EPI == EPI_F32_RESID) {
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {          // two batches of 8 rows: 8 loads in flight per lane, no spills
-          float4 r[8];
-#pragma unroll
-          for (int it = 0; it < 8; ++it) r[it] = *(const float4*)(obase + (size_t)(hb * 8 + it) * ldo);
-#pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            const int row = wave * 16 + hb * 8 + it;
-            const float4 v = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 63)) << 4));
-            r[it].x += v.x; r[it].y += v.y; r[it].z += v.z; r[it].w += v.w;
-            *(float4*)(obase + (size_t)(hb * 8 + it) * ldo) = r[it];
-          }
-        }
-      } else {
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-          const int row = wave * 16 + it;
-          *(float4*)(obase + (size_t)it * ldo) = *(const float4*)(smem + row * 1024 + ((lane ^ (row & 63)) << 4));
-        }
-      }
     }
   }
 }
@@ -257,11 +338,15 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
 // ------------------------------------------------------------------------------------------------
 // ABL (micro-benchmark ablations only): 0 = real kernel, 1 = no LDS-DMA inside the K loop (tile 0 reused),
 // 2 = no MFMA (fragments kept alive), 3 = no ds_read (fragments loaded once)
-template <int EPI, int ABL = 0, int GM = 4>
+template <int EPI, int ABL = 0, int GM = 4, int PC = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int stagger) {
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
+  if (stagger > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < stagger) __builtin_amdgcn_s_sleep(32);
+  }
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
 
   const int lane = threadIdx.x & 63;
@@ -298,13 +383,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   const size_t piece_stride = (size_t)16 * lds_;
   const int lds_piece0 = (stage_w ? 256 * 64 : 0) + (wave & 3) * 4 * 1024;  // byte offset inside a half-buffer
 
-  auto stage_half = [&](int t, int kk) {
+  auto stage_pieces = [&](int t, int kk, int i0, int i1) {
     char* hb = smem + ((t & 1) * 2 + kk) * HALF_BYTES + lds_piece0;
     const bf16_t* g = gsrc + (size_t)t * 64 + kk * 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = i0; i < i1; ++i)
       __builtin_amdgcn_global_load_lds(PG_GLB_PTR(g + i * piece_stride), PG_LDS_PTR(hb + i * 1024), 16, 0, 0);
   };
+  auto stage_half = [&](int t, int kk) { stage_pieces(t, kk, 0, 4); };
 
   f32x4 acc[4][8];
 #pragma unroll
@@ -312,10 +398,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / 64;
+  const int nk = K / 64;                            // >= 2 (launcher)
   stage_half(0, 0);
   stage_half(0, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage_half(1, 0);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // half-step 0 landed; 1 and 2 stay in flight
   __syncthreads();
   if (grp == 1) __builtin_amdgcn_s_barrier();      // stagger the two groups by one barrier interval
 
@@ -325,23 +412,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   const int woff = 256 * 64 + (wn * 64) * 64 + foff;
 
   bf16x8 wf[4], xf[8];
-  for (int t = 0; t < nk; ++t) {
-    const bool has_next = (t + 1 < nk);
+  for (int t = 0; t < (ABL == 13 ? 1 : nk); ++t) {          // ABL 13: one K-tile only -> times prologue + epilogue
+    const bool has1 = (t + 1 < nk) && ABL != 13, has2 = (t + 2 < nk) && ABL != 13;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      // ---------------- L segment: fragments of (t, kk) + DMA of (t+1, kk) ----------------
+      // ---------------- L segment: fragments of half-step s = (t, kk) + DMA of half-step s+3 ----------------
       constexpr bool NO_DMA = (ABL == 1 || ABL == 8 || ABL == 9 || ABL == 11), NO_DS = (ABL == 3 || ABL == 8 || ABL == 9 || ABL == 11 || ABL == 12),
                      NO_BAR = (ABL == 9 || ABL == 11 || ABL == 12);
       const char* hb = smem + (((NO_DMA ? 0 : (t & 1)) * 2) + kk) * HALF_BYTES;
-      if (has_next && !NO_DMA) stage_half(t + 1, kk);
+      const bool issue = kk == 0 ? has1 : has2;
+      if (issue && !NO_DMA) {
+        if (kk == 0) stage_pieces(t + 1, 1, 0, 4 - PC); else stage_pieces(t + 2, 0, 0, 4 - PC);
+      }
       if (!NO_DS || t == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(hb + woff + i * 1024);
 #pragma unroll
         for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(hb + xoff + j * 1024);
       }
-      if (has_next && !NO_DMA) {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // all but the 4 pieces just issued
+      // half-step s+1 must have landed before the barrier; s+2 and s+3 (4 pieces each) may stay in flight
+      if (NO_DMA) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if (ABL == 15) {                                         // timing only: never wait for the DMA
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if (issue) {
+        if (PC == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        if (PC == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+        if (PC == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      } else if (kk == 1 && has1) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // (t+1,0) needed, (t+1,1) in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
@@ -352,10 +451,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       __builtin_amdgcn_s_setprio(1);
       if (ABL != 2 && ABL != 12) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          // PC of the 4 DMA pieces ride in the MFMA stream (cheaper to issue there than in the loaded L segment)
+          if (PC > 0 && issue && !NO_DMA && i < PC) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 0) stage_pieces(t + 1, 1, 4 - PC + i, 5 - PC + i); else stage_pieces(t + 2, 0, 4 - PC + i, 5 - PC + i);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]));
@@ -389,29 +495,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 // full loop without epilogue 0.60 ms, with the coalesced epilogue 0.71 ms (was 0.79 ms with per-lane stores).
 
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi, int abl = 0) {
+                     int ldx, int ldw, int ldo, int epi, int abl = 0, int pc = 0) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles), block(512);
+  static const int stagger_pct = [] { const char* e = getenv("PGIBBS_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
+  const int stagger = (n_tiles >= 512) ? (int)((long long)stagger_pct * (K / 64) * 3000 / 100) : 0;
   if (abl) {   // ablations: EPI_BF16 only
-    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 13) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 14) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 15) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 15>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
     PG_HIP(hipGetLastError());
     return 0;
   }
-#define PG_GEMM_CASE(E)                                                                                        \
-  case E:                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, \
-                       n_tiles);                                                                               \
+#define PG_GEMM_CASE(E)                                                                                                   \
+  case E:                                                                                                                 \
+    if (pc == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 4, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
+    else if (pc == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 4, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
+    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
@@ -499,7 +611,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
       v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
     }
     float v0 = v[0] + b4.x, v1 = v[1] + b4.y, v2 = v[2] + b4.z, v3 = v[3] + b4.w;
-    if (EPI == EPI_BF16_GELU || EPI == EPI_F32_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+    if (EPI == EPI_F32_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+    if (EPI == EPI_BF16_GELU) { v0 = gelu_bf16out(v0); v1 = gelu_bf16out(v1); v2 = gelu_bf16out(v2); v3 = gelu_bf16out(v3); }
     const size_t o = (size_t)(t * 16 + fr) * ldo + n0 + fq * 4;
     if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
       uint2 p;
@@ -551,7 +664,7 @@ static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const flo
 #define PG_GEMM_CASE(E)                                                                                              \
   case E:                                                                                                            \
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, \
-                       tiles_n, n_tiles);                                                                            \
+                       tiles_n, n_tiles);                                                                   \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
@@ -585,10 +698,10 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
     return launch_skinny_mt<16>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
   }
   if (M % 128 || N % 128 || K % 64) return fail(1, "gemm: M,N must be multiples of 128 and K of 64");
-  if (M % 256 == 0 && N % 256 == 0 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
+  if (M % 256 == 0 && N % 256 == 0 && K >= 128 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
   // (Peeling the 1-3 % full last round of tiles into a trailing 128x128 launch was measured: no gain -- blocks do not
   //  run in lockstep rounds, the dispatcher back-fills -- so every 256-multiple shape goes to one launch.)
-  if (M % 256 == 0 && N % 256 == 0 && variant >= 2) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  if (M % 256 == 0 && N % 256 == 0 && K >= 128 && variant >= 2) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0, variant == 3 ? 1 : (variant == 4 ? 2 : 0));
   if (M % 256 == 0 && N % 256 == 0) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }

@@ -25,18 +25,24 @@ def _gelu(x):
                                        (1000, 512, 5120, 1),
                                        # skinny (M <= 64) weight-streaming kernel
                                        (27, 1280, 1280, 0), (1, 128, 64, 0), (16, 3840, 1280, 1), (64, 1280, 5120, 0), (33, 256, 192, 1),
-                                       (100, 1280, 1280, 0), (216, 5120, 1280, 1), (256, 768, 3072, 0), (129, 128, 64, 0)])
+                                       (100, 1280, 1280, 0), (216, 5120, 1280, 1), (256, 768, 3072, 0), (129, 128, 64, 0),
+                                       # epi 2 = residual read-modify-write (out += x w^T + b): 256^2, 128^2 and skinny kernels
+                                       (513, 1280, 1280, 2), (700, 1280, 320, 2), (300, 384, 256, 2), (40, 1280, 5120, 2),
+                                       (512, 1280, 320, 0), (512, 1280, 320, 1), (300, 256, 64, 2)])
 def test_gemm_bf16(M, N, K, epi):
     rng = np.random.default_rng(M + N + K)
     x = rng.standard_normal((M, K), dtype=np.float32)
     w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
     x[:, 0] += np.arange(M, dtype=np.float32) * 0.01        # break any row/col symmetry
     b = rng.standard_normal(N, dtype=np.float32)
-    out = np.empty((M, N), dtype=np.float32)
+    out = rng.standard_normal((M, N), dtype=np.float32) * 3
+    res0 = out.astype(np.float64)
     _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_BF16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
     ref = _bf16(x).astype(np.float64) @ _bf16(w).astype(np.float64).T + b
-    if epi:
+    if epi == 1:
         ref = _gelu(ref)
+    if epi == 2:
+        ref = ref + res0
     err = np.abs(out - ref).max()
     assert err < 2e-3 * max(1.0, np.abs(ref).max()), err      # fp32 accumulation-order noise only
 
