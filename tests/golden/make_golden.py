@@ -40,8 +40,9 @@ def standin_tables():
     return (g.standard_normal((40, 33), dtype=np.float32), g.standard_normal((2048, 33), dtype=np.float32))
 
 
-def _standin(arch):
-    """arch: 'esm1b' (bos+eos, mask=32) or 'msa1b' (bos only)."""
+def _standin(arch, context=False):
+    """arch: 'esm1b' (bos+eos, mask=32) or 'msa1b' (bos only).  context=True (MSA only): the logits of a row also depend on
+    the other rows of its MSA (mean over rows), so a wrong context alignment changes the scores."""
     import re
     import torch
 
@@ -106,6 +107,8 @@ def _standin(arch):
             right = torch.roll(tokens, -1, dims=-1)
             logits = self.tab[tokens] + 0.5 * self.tab[left].roll(3, -1) + 0.25 * self.tab[right].roll(7, -1) \
                 + self.ptab[:L]
+            if context:
+                logits = logits + 0.75 * self.tab[tokens].mean(dim=-3, keepdim=True).roll(5, -1)
             return {"logits": logits}
 
     class Model:

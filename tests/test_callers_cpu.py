@@ -1,0 +1,137 @@
+"""Host-side callers either side of the Gibbs path: alignment helpers against outputs recorded
+from the reference (tests/golden/callers.json, made by tests/golden/make_golden_callers.py), the reference's own KATs
+for `unalign` / `add_gaps_back` (test/test_utils.py:76-89), the HMMER3 report parser and the command-line surfaces."""
+import subprocess
+
+import pytest
+
+from protein_gibbs_sampler_amd import (clean_fasta, likelihood_esm, likelihood_esm_msa, msa_tools, pgen_esm_from_fasta,
+                                       pgen_msa_revised)
+from _standin import load_json
+
+G = load_json("callers.json")
+
+
+def test_helpers_match_reference_recordings():
+    h = G["helpers"]
+    for s, (clean, mask) in h["unalign"]:
+        assert list(msa_tools.unalign(s)) == [clean, mask]
+    for a, m, want in h["add_gaps_back"]:
+        assert msa_tools.add_gaps_back(a, m) == want
+    for m, c, want in h["delete_msa_cols"]:
+        assert msa_tools.delete_msa_cols(m, c) == want
+    for m, want in h["count_gaps"]:
+        assert msa_tools.count_gaps_per_column(m) == want
+    for m, t, want in h["gap_threshold"]:
+        assert msa_tools.apply_gap_threshold(m, t) == want
+
+
+@pytest.mark.parametrize("seq,expected", [
+    (".*-ABCDE.*-", ("ABCDE", [".", "*", "-", None, None, None, None, None, ".", "*", "-"])),
+    ("AB.*-AB", ("ABAB", [None, None, ".", "*", "-", None, None])),
+])
+def test_unalign_kat(seq, expected):
+    assert msa_tools.unalign(seq) == expected
+    assert msa_tools.add_gaps_back(*expected) == seq
+
+
+def test_add_gaps_back_kat():
+    assert msa_tools.add_gaps_back("MTGQ", [None, "-", "-", None, None, ".", "-", None, "*"]) == "M--TG.-Q*"
+
+
+def test_write_partitioned_fasta(tmp_path):
+    p = tmp_path / "x.fasta"
+    msa_tools.write_partitioned_fasta(p, {"1": ["AAA", "CC"], "ref": ["G"]})
+    assert p.read_text() == ">1_0\nAAA\n>1_1\nCC\n>ref_0\nG\n"
+
+
+PHMMER_REPORT = """# phmmer :: search a protein sequence against a protein database
+# HMMER 3.3.2 (Nov 2020); http://hmmer.org/
+# - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - -
+# query sequence file:             /tmp/x/query.fa
+# target sequence database:        /tmp/db.fasta
+# - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - - -
+
+Query:       QUERY  [L=193]
+Scores for complete sequences (score includes all domains):
+   --- full sequence ---   --- best 1 domain ---    -#dom-
+    E-value  score  bias    E-value  score  bias    exp  N  Sequence Description
+    ------- ------ -----    ------- ------ -----   ---- --  -------- -----------
+    1.1e-58  187.1   0.1    1.3e-58  186.9   0.1    1.0  1  2         
+    2.2e-40  127.5   0.0    2.5e-40  127.3   0.0    1.0  1  0         some description here
+  ------ inclusion threshold ------
+      0.012   12.0   0.0      0.015   11.7   0.0    1.2  1  3         
+
+
+Domain annotation for each sequence:
+>> 2  
+   #    score  bias  c-Evalue  i-Evalue hmmfrom  hmm to    alifrom  ali to    envfrom  env to     acc
+ ---   ------ ----- --------- --------- ------- -------    ------- -------    ------- -------    ----
+   1 !  186.9   0.1   9.9e-59   1.3e-58       2     192 ..       1     190 [.       1     191 [. 0.98
+
+Internal pipeline statistics summary:
+-------------------------------------
+Query sequence(s):                         1  (193 residues searched)
+//
+[ok]
+"""
+
+
+def test_parse_phmmer_hits():
+    assert msa_tools.parse_phmmer_hits(PHMMER_REPORT) == ["2", "0", "3"]
+    empty = PHMMER_REPORT.split("    1.1e-58")[0] + "\n   [No hits detected that satisfy reporting thresholds]\n\n\nDomain annotation for each sequence:\n"
+    assert msa_tools.parse_phmmer_hits(empty) == []
+
+
+def test_external_tools_fail_loudly_when_absent(monkeypatch):
+    def missing(*a, **k):
+        raise FileNotFoundError
+    monkeypatch.setattr(subprocess, "run", missing)
+    for call in (lambda: msa_tools.run_phmmer("ACD", "/nonexistent.fasta"), lambda: msa_tools.generate_alignment({"1": ["ACD", "AC"]}),
+                 lambda: msa_tools.add_to_msa(["ACD"], "AC")):
+        with pytest.raises(Exception, match="not found on PATH"):
+            call()
+
+
+def test_command_line_surfaces():
+    """Every flag of the reference front ends is accepted (pgen_msa_revised.py:119-146, pgen_esm_from_fasta.py:62-68,
+    likelihood_esm.py:65-74, likelihood_esm_msa.py:154-175, clean_fasta.py:7-11)."""
+    a = pgen_msa_revised.build_parser().parse_args(
+        "--templates t.fa --references r.fa -o out.fa --seqs_per_template 2 --keep_identical --steps 5 --passes 2 --burn_in 1 "
+        "--top_k 3 --legacy --gap_percent_threshold 49 --ep 0.1 --op 2 --device cuda:0 --model esm_msa1 --alignment_size 8 --debug".split())
+    assert (a.seqs_per_template, a.steps, a.passes, a.burn_in, a.top_k, a.alignment_size) == (2, 5, 2, 1, 3, 8)
+    assert a.legacy and a.debug and a.keep_identical and a.gap_percent_threshold == 49.0 and (a.ep, a.op) == (0.1, 2.0)
+    d = pgen_msa_revised.build_parser().parse_args("--templates t --references r -o o".split())
+    assert (d.steps, d.passes, d.burn_in, d.top_k, d.alignment_size, d.gap_percent_threshold, d.ep, d.op) == (10, 3, 1, 1, 32, 80.0, 0.0, 1.53)
+    b = pgen_esm_from_fasta.build_parser().parse_args("-o out -i spec.tsv --num_output_sequences 4 --model esm1b --keep_gap_positions".split())
+    assert b.num_output_sequences == 4 and b.keep_gap_positions and b.batch_size == 1
+    with pytest.raises(SystemExit):
+        pgen_esm_from_fasta.build_parser().parse_args("--batch_size 2".split())
+    c = likelihood_esm.build_parser().parse_args("-i in.fa -o out.tsv --batch_size 4 --masking_off --model esm1b --csv --score_name s "
+                                                 "--positionwise p.tsv".split())
+    assert c.batch_size == 4 and c.masking_off and c.csv and c.score_name == "s" and c.positionwise == "p.tsv" and c.mask_distance is None
+    assert likelihood_esm.build_parser().parse_args([]).model == "esm1v"
+    e = likelihood_esm_msa.build_parser().parse_args(
+        "-i in.fa -o o.tsv --reference_msa ref.fa --delete_insertions --alignment_size 31 --keep_identical --batch_size 2 "
+        "--subset_strategy top_hits --subset_random_seed 3 --redraw --unaligned_queries --mask_distance 5 --csv --positionwise p".split())
+    assert e.subset_strategy == "top_hits" and e.alignment_size == 31 and e.subset_random_seed == 3 and e.redraw and e.unaligned_queries
+    with pytest.raises(SystemExit):
+        likelihood_esm_msa.build_parser().parse_args([])          # --reference_msa is required
+
+
+def test_likelihood_cli_argument_errors(monkeypatch):
+    with pytest.raises(ValueError, match="mask distance must be an integer >= 1"):
+        likelihood_esm.cli(["--mask_distance", "0"])
+    with pytest.raises(ValueError, match="both set"):
+        likelihood_esm.cli(["--mask_distance", "2", "--masking_off"])
+    with pytest.raises(ValueError, match="redraw is set"):
+        likelihood_esm_msa.cli(["--reference_msa", "x", "--redraw", "--subset_strategy", "in_order"])
+
+
+def test_clean_fasta(tmp_path):
+    src, dst = tmp_path / "in.fa", tmp_path / "out.fa"
+    src.write_text(G["inputs"]["fasta_gapped"])
+    clean_fasta.main(["-i", str(src), "-o", str(dst), "--clean_strategy", "unalign"])
+    assert dst.read_text() == ">s1\nMKVAA\n>s2\nACDEF\n>s3\nGHIK\n"
+    clean_fasta.main(["-i", str(src), "-o", str(dst), "--clean_strategy", "delete", "--full_name"])
+    assert dst.read_text() == ">s1 desc\nMK-VAA\n>s2\n-DEF\n>s3\n--GHIK--\n"
