@@ -382,8 +382,16 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
   if ((rc = launch_f32_to_bf16(nullptr, dx, bx, (int64_t)Mp * K, 1.f))) return rc;
   if ((rc = launch_f32_to_bf16(nullptr, dw, bw, (int64_t)N * K, 1.f))) return rc;
   if (epi == 2) PG_HIP(hipMemcpy(dout, out, (size_t)M * N * 4, hipMemcpyHostToDevice));     // residual variant: out += x w^T + b
-  if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
-                             epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32)))) return rc;
+  if (epi == 3 || epi == 4) {                       // bf16 outputs (the QKV / fc1 epilogues), widened to fp32 for the caller
+    bf16_t* bout = (bf16_t*)t.get((size_t)Mp * N * 2);
+    if (!bout) return fail(PG_ERR_HIP, "hipMalloc failed");
+    if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, bout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
+                               epi == 4 ? EPI_BF16_GELU : EPI_BF16))) return rc;
+    if ((rc = launch_bf16_to_f32(nullptr, bout, dout, (int64_t)M * N))) return rc;
+  } else if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
+                                    epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32)))) {
+    return rc;
+  }
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
   return PG_OK;

@@ -190,7 +190,7 @@ __device__ __forceinline__ void buf_store_f32x4(f32x4 v, rsrc_t rs, int voff, in
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, bool NO_STORE = false>
 __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int wm, int wn, int wave, int lane, int m0,
                                              int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo) {
   const int fr = lane & 15, fq = lane >> 4;
@@ -312,6 +312,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
     for (int it = 0; it < 16; ++it) {
       const int row = (wave * 16 + it) * 2 + (lane >> 5);
       const uint4 v = *(const uint4*)(smem + row * 512 + ((c ^ (row & 31)) << 4));
+      if (NO_STORE) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }    // ablation: all but the global stores
       *(uint4*)((bf16_t*)out + (size_t)(m0 + row) * ldo + n0 + c * 8) = v;
     }
   }
@@ -338,15 +339,11 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
 // ------------------------------------------------------------------------------------------------
 // ABL (micro-benchmark ablations only): 0 = real kernel, 1 = no LDS-DMA inside the K loop (tile 0 reused),
 // 2 = no MFMA (fragments kept alive), 3 = no ds_read (fragments loaded once)
-template <int EPI, int ABL = 0, int GM = 4, int PC = 0>
+template <int EPI, int ABL = 0, int GM = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int stagger) {
+                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
-  if (stagger > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-    const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < stagger) __builtin_amdgcn_s_sleep(32);
-  }
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
 
   const int lane = threadIdx.x & 63;
@@ -403,7 +400,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   stage_half(0, 1);
   stage_half(1, 0);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // half-step 0 landed; 1 and 2 stay in flight
-  __syncthreads();
+  __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();      // stagger the two groups by one barrier interval
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -422,7 +419,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       const char* hb = smem + (((NO_DMA ? 0 : (t & 1)) * 2) + kk) * HALF_BYTES;
       const bool issue = kk == 0 ? has1 : has2;
       if (issue && !NO_DMA) {
-        if (kk == 0) stage_pieces(t + 1, 1, 0, 4 - PC); else stage_pieces(t + 2, 0, 0, 4 - PC);
+        if (kk == 0) stage_half(t + 1, 1); else stage_half(t + 2, 0);
       }
       if (!NO_DS || t == 0) {
 #pragma unroll
@@ -436,9 +433,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       } else if (ABL == 15) {                                         // timing only: never wait for the DMA
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if (issue) {
-        if (PC == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        if (PC == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-        if (PC == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       } else if (kk == 1 && has1) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // (t+1,0) needed, (t+1,1) in flight
       } else {
@@ -451,17 +446,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       __builtin_amdgcn_s_setprio(1);
       if (ABL != 2 && ABL != 12) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-          // PC of the 4 DMA pieces ride in the MFMA stream (cheaper to issue there than in the loaded L segment)
-          if (PC > 0 && issue && !NO_DMA && i < PC) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk == 0) stage_pieces(t + 1, 1, 4 - PC + i, 5 - PC + i); else stage_pieces(t + 2, 0, 4 - PC + i, 5 - PC + i);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]));
@@ -483,47 +471,54 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  epilogue_256<EPI>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
+  epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
 }
 
-// Measured alternatives that were NOT faster on MI355X and were removed again (numbers: QKV GEMM, M=66048 N=3840 K=1280):
-//   * "v3" -- all waves in lockstep, DMA pieces and fragment prefetch interleaved after every 4 MFMAs, 4-slot ring,
-//     one barrier per half-step: 855 TF vs 920 TF for the ping-pong kernel;
-//   * ping-pong on v_mfma_f32_32x32x16_bf16: 761 TF (identical SQ_VALU_MFMA_BUSY_CYCLES, more issue stalls);
-//   * peeling the partial last round of tiles into a 128x128 launch: no gain (blocks do not run in lockstep rounds).
-// Ablations of the ping-pong kernel (tools/gemm_bench.py variants 21-32): MFMA-only 0.43 ms, DMA-only 0.32 ms,
-// full loop without epilogue 0.60 ms, with the coalesced epilogue 0.71 ms (was 0.79 ms with per-lane stores).
-
+// Measured alternatives that were NOT faster on MI355X and were removed again (QKV GEMM, M=66048 N=3840 K=1280, steady-state
+// clocks -- time >= 300 launches: the first ~10 ms after idle run at ramping clocks and mislead):
+//   * "v3" -- all waves in lockstep, DMA pieces and fragment prefetch interleaved after every 4 MFMAs, one barrier per
+//     half-step; ping-pong on v_mfma_f32_32x32x16_bf16 (same MFMA busy cycles, more issue stalls);
+//   * 1 or 2 of the 4 DMA pieces issued inside the MFMA segment: -1 % / -2 %;
+//   * half of the first round's workgroups started half a tile late (to de-phase the chip-wide store bursts): 0 ... -2 %;
+//   * peeling the partial last round of tiles into a 128x128 launch: no gain (the dispatcher back-fills);
+//   * touching the residual tile's cache lines at the start of the main loop (so that the read half of the epilogue's
+//     read-modify-write is spread out): out-proj 0.31 -> 0.35 ms;
+//   * a persistent kernel (one workgroup per CU; after a tile, waves 0-3 store it from 64 KB of LDS staging while waves
+//     4-7 issue the next tile's first three half-steps of DMA; the split is by wave because vmcnt counts stores too):
+//     QKV +1.2 %, fc1 +2 %, fp32-residual outputs -7 % (only 4 waves doing the read-modify-write), whole iteration +0.2 %.
+// Where the time goes (tools/gemm_bench.py variants 21-36, tools/epi_cost.py): MFMA-only loop 0.30 ms, LDS-DMA + ds_read +
+// barriers without MFMA 0.34, both 0.47 (not DMA latency: never waiting for the DMA gives the same time; a deeper ring
+// changes nothing), prologue + one K-tile + epilogue 0.12.  The epilogue cost is the chip-wide HBM burst: it scales with
+// the bytes (bf16 0.09, fp32 0.16, fp32 read-modify-write 0.32 ms at this shape = 5.5-6.3 TB/s), a lone workgroup's
+// epilogue takes < 2 us against 6 us per tile when all 256 CUs store together.  The vendor BLAS runs the same four shapes
+// without any epilogue at 1245-1273 TFLOP/s.
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi, int abl = 0, int pc = 0) {
+                     int ldx, int ldw, int ldo, int epi, int abl = 0) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles), block(512);
-  static const int stagger_pct = [] { const char* e = getenv("PGIBBS_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-  const int stagger = (n_tiles >= 512) ? (int)((long long)stagger_pct * (K / 64) * 3000 / 100) : 0;
   if (abl) {   // ablations: EPI_BF16 only
-    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 13) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 14) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 15) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 15>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 13) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 14) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 16) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 15) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 15>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
     PG_HIP(hipGetLastError());
     return 0;
   }
 #define PG_GEMM_CASE(E)                                                                                                   \
   case E:                                                                                                                 \
-    if (pc == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 4, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
-    else if (pc == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 4, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
-    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
@@ -701,7 +696,7 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   if (M % 256 == 0 && N % 256 == 0 && K >= 128 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
   // (Peeling the 1-3 % full last round of tiles into a trailing 128x128 launch was measured: no gain -- blocks do not
   //  run in lockstep rounds, the dispatcher back-fills -- so every 256-multiple shape goes to one launch.)
-  if (M % 256 == 0 && N % 256 == 0 && K >= 128 && variant >= 2) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0, variant == 3 ? 1 : (variant == 4 ? 2 : 0));
+  if (M % 256 == 0 && N % 256 == 0 && K >= 128 && variant >= 2) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (M % 256 == 0 && N % 256 == 0) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }

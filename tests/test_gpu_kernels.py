@@ -28,7 +28,11 @@ def _gelu(x):
                                        (100, 1280, 1280, 0), (216, 5120, 1280, 1), (256, 768, 3072, 0), (129, 128, 64, 0),
                                        # epi 2 = residual read-modify-write (out += x w^T + b): 256^2, 128^2 and skinny kernels
                                        (513, 1280, 1280, 2), (700, 1280, 320, 2), (300, 384, 256, 2), (40, 1280, 5120, 2),
-                                       (512, 1280, 320, 0), (512, 1280, 320, 1), (300, 256, 64, 2)])
+                                       (512, 1280, 320, 0), (512, 1280, 320, 1), (300, 256, 64, 2),
+                                       # epi 3 / 4 = bf16 outputs (QKV / fc1 epilogues): one-shot 256^2, 128^2, skinny ...
+                                       (513, 1280, 1280, 3), (700, 1280, 320, 4), (300, 384, 256, 3), (40, 1280, 5120, 4),
+                                       # ... and >= 2 tiles per CU: the persistent kernel (ragged XCD shares, odd K-tile count)
+                                       (8192, 4096, 256, 3), (8192 + 256, 4096 + 256, 320, 4), (16384, 2304, 128, 3)])
 def test_gemm_bf16(M, N, K, epi):
     rng = np.random.default_rng(M + N + K)
     x = rng.standard_normal((M, K), dtype=np.float32)
@@ -39,10 +43,14 @@ def test_gemm_bf16(M, N, K, epi):
     res0 = out.astype(np.float64)
     _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_BF16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
     ref = _bf16(x).astype(np.float64) @ _bf16(w).astype(np.float64).T + b
-    if epi == 1:
+    if epi in (1, 4):
         ref = _gelu(ref)
     if epi == 2:
         ref = ref + res0
+    if epi >= 3:                                               # bf16 result: half an ulp (2^-9 relative) on top
+        assert (np.abs(out - ref) <= 2e-3 * max(1.0, np.abs(ref).max()) + np.abs(ref) * 2.0 ** -8).all()
+        assert (out == _bf16(out)).all()
+        return
     err = np.abs(out - ref).max()
     assert err < 2e-3 * max(1.0, np.abs(ref).max()), err      # fp32 accumulation-order noise only
 
