@@ -495,7 +495,7 @@ int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, in
   if ((rc = launch_f32_to_bf16(nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
   if (which == 0) {
     // scratch for the split-R mode (taken when B*H*ceil(C/64) < 384 and R >= 8), so the tests exercise both modes
-    const size_t pbytes = (size_t)B * H * 16 * C * 576 * 4;
+    const size_t pbytes = (size_t)B * H * 16 * C * 576 * 4 + (size_t)B * H * (C / 16 + 9) * 18 * 1024;
     float* part = pbytes <= ((size_t)1 << 30) ? (float*)t.get(pbytes) : nullptr;
     if ((rc = launch_msa_row_attention_bf16(nullptr, bq, bc, B, R, C, H, 3 * d, d, d, 2 * d, scale, part, part ? pbytes : 0))) return rc;
   } else {

@@ -503,7 +503,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     if (C <= 576) {
       float* part = nullptr;
       if (B * H * ((C + 63) / 64) < 384 && R >= 8) {      // few workgroups: give the kernel scratch for its split-R mode
-        const size_t need = (size_t)B * H * 16 * C * 576 * 4;
+        const size_t need = (size_t)B * H * 16 * C * 576 * 4 + (size_t)B * H * (C / 16 + 9) * 18 * 1024;   // partial maps + P fragments
         if (need <= ((size_t)1 << 31) && !(rc = scores.ensure(need, stream))) part = scores.as<float>();
       }
       if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0); }))) return rc;

@@ -4,12 +4,16 @@
 //   P = softmax_j(A);   ctx[r,i,h,:] = sum_j P[h,i,j] v[r,j,h,:]
 // (Column attention is the plain fused attention kernel over strided sequences: attention.hip.)
 //
-// One workgroup = (msa b, head h, 64 queries); wave w owns 16 of them.  Pass 1 streams K_r (C x 64) through LDS for
+// One workgroup = (msa b, head h, NW*16 queries); wave w owns 16 of them.  Pass 1 streams K_r (C x 64) through LDS for
 // r = 0..R-1 and accumulates the S^T blocks of the wave's 16 queries in registers with v_mfma_f32_16x16x32_bf16
 // (the same lane-local layout as attention.hip: a lane holds one query's scores for 4 keys of every 16-key block),
 // then one exact softmax; pass 2 streams V_r^T through LDS and emits ctx for every row with the same P fragments.
-// Row r+1's tile is fetched into registers while row r's MFMAs run, and the query chunks of one (msa, head) are
-// placed on one XCD so the re-streamed tiles hit its L2.
+// Every workgroup of a (msa, head) re-streams all R tiles, so the workgroup is made as wide as the registers allow:
+// NW = 9 waves cover C = 257 columns (bos + 256) in 2 workgroups instead of 5 (the 5th held a single query).
+// The tiles alternate between two LDS buffers (one barrier per row) and are fetched into registers two rows ahead
+// (one for the widest tiles); measured at 64 MSAs x 32 x 257: 1.79 -> 1.31 ms per layer, of which the strided K / V / Q
+// tile loads (128 contiguous bytes per token row) are 0.55 ms and the MFMAs 0.1 ms;
+// the query chunks of one (msa, head) are placed on one XCD so the re-streamed tiles hit its L2.
 #include "kernels.h"
 
 namespace pg {
@@ -17,29 +21,36 @@ namespace pg {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int MAXKB>
-__global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_kernel(
+template <int MAXKB, int NW, int mode>
+__global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int R, int C, int H, int ld_qkv, int ld_ctx, int k_off,
-    int v_off, float scale, int n_qblk, int n_bh, int mode, int n_rc, float* __restrict__ partial) {
+    int v_off, float scale, int n_qblk, int n_bh, int n_rc, float* __restrict__ partial) {
   // mode 0: fused (both passes over all R rows).  Split-R (few (msa, head) pairs, e.g. generate_single with B = 1):
   // mode 1: pass 1 over the row chunk rc only, partial S^T -> partial[bh][rc][query][key];
-  // mode 2: S = sum of the n_rc partial maps, softmax, pass 2 over the row chunk rc only.
+  // mode 3: (one workgroup per (msa, head, query block)) S = sum of the n_rc partial maps in fixed order, softmax,
+  //         P as bf16 MFMA fragments -> pfrag (16 B per lane and fragment, stored behind the partial maps);
+  // mode 2: pass 2 over the row chunk rc only with the P fragments of mode 3.
   constexpr int VT_LD = MAXKB * 16 + 8;
   constexpr int tpad = MAXKB * 16, hpad = tpad / 2;
-  constexpr int NIT = (tpad * 8 + 255) / 256;      // K items per thread: one uint4 = 8 d of one key
-  constexpr int NVP = (hpad * 8 + 255) / 256;      // V items per thread: two adjacent keys x 8 d
-  __shared__ __attribute__((aligned(16))) char smem[MAXKB * 16 * 128 + 64 * VT_LD * 2];
-  char* Ks = smem;
-  bf16_t* Vt = (bf16_t*)(smem + MAXKB * 16 * 128);
+  constexpr int NT = NW * 64;                      // threads
+  constexpr int NIT = (tpad * 8 + NT - 1) / NT;    // K items per thread: one uint4 = 8 d of one key
+  constexpr int NVP = (hpad * 8 + NT - 1) / NT;    // V items per thread: two adjacent keys x 8 d
+  constexpr int AHEAD = (MAXKB <= 18 && NIT <= 9) ? 2 : 1;   // rows fetched ahead into registers (register budget)
+  constexpr int BUF = 64 * VT_LD * 2;              // one tile buffer: V^T (64 x VT_LD bf16) >= K (tpad x 128 B)
+  static_assert(BUF >= MAXKB * 16 * 128, "tile buffer");
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // mode 3 is launched with one wave per workgroup (the reduction has no LDS phase; this spreads it over the chip):
+  // blockIdx carries the wave slot
+  const int tid = threadIdx.x, lane = tid & 63, wave = mode == 3 ? (int)(blockIdx.x % NW) : tid >> 6;
+  const int blk = mode == 3 ? (int)(blockIdx.x / NW) : (int)blockIdx.x;
   // XCD-aware mapping (block b runs on XCD b % 8): the query chunks of one (msa, head) get consecutive slots of ONE
   // XCD, so the K_r / V_r tiles they all stream are served by that XCD's L2 after the first touch.
   int qblk, bh;
   const int per_rc = n_bh * n_qblk;
-  const int rc = blockIdx.x / per_rc;                // row chunk (0 in fused mode)
+  const int rc = blk / per_rc;                       // row chunk (0 in fused mode)
   {
-    const int bidx = blockIdx.x - rc * per_rc;
+    const int bidx = blk - rc * per_rc;
     const int xcd = bidx & 7, slot = bidx >> 3;
     const int full = (n_bh / 8) * 8;                 // (msa, head) pairs covered by the XCD-aligned part of the grid
     if (bidx < full * n_qblk) {
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
   const int b = bh / H, h = bh % H;
   const bf16_t* base = qkv + (size_t)b * R * C * ld_qkv + h * 64;   // row (r*C + i)
   const int fr = lane & 15, fq = lane >> 4;
-  const int q0 = qblk * 64 + wave * 16;
+  const int q0 = qblk * (NW * 16) + wave * 16;
   const bool active = q0 < C;                                      // wave-uniform
   int qrow = q0 + fr;
   if (qrow >= C) qrow = C - 1;
@@ -66,41 +77,53 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
 #pragma unroll
   for (int kb = 0; kb < MAXKB; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- pass 1: scores summed over rows.  The K tile of row r+1 is fetched into registers while row r's MFMAs run.
-  uint4 kreg[NIT];
-  auto load_k = [&](int r) {
+  // ---- pass 1: scores summed over rows.  Tile r goes to LDS buffer r & 1; the registers it came from are refilled with
+  // row r + 2 right away, so a tile has two rows of MFMAs to arrive.
+  struct KRegs { uint4 k[NIT]; };                    // one row's K tile share
+  KRegs kA, kB;
+  auto load_k = [&](KRegs& g, int r) {
     const bf16_t* rb = base + (size_t)r * C * ld_qkv;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * 256, row = i >> 3, c = i & 7;
-      kreg[it] = make_uint4(0, 0, 0, 0);
-      if (i < tpad * 8 && row < C) kreg[it] = *(const uint4*)(rb + (size_t)row * ld_qkv + k_off + c * 8);
+      const int i = tid + it * NT, row = i >> 3, c = i & 7;
+      g.k[it] = make_uint4(0, 0, 0, 0);
+      if (i < tpad * 8 && row < C) g.k[it] = *(const uint4*)(rb + (size_t)row * ld_qkv + k_off + c * 8);
     }
   };
-  if (mode != 2 && r_lo < r_hi) load_k(r_lo);
-  for (int r = r_lo; r < r_hi && mode != 2; ++r) {
-    __syncthreads();                                  // previous tile fully consumed
+  auto score_row = [&](KRegs& g, int r) {
+    char* Ks = smem + (r & 1) * BUF;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * 256, row = i >> 3, c = i & 7;
-      if (i < tpad * 8) *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
+      const int i = tid + it * NT, row = i >> 3, c = i & 7;
+      if (i < tpad * 8) *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = g.k[it];
     }
-    __syncthreads();
-    if (r + 1 < r_hi) load_k(r + 1);                  // in flight during the MFMAs below
+    const bf16_t* qp = base + ((size_t)r * C + qrow) * ld_qkv + fq * 8;     // in flight across the barrier
+    const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
+    __syncthreads();                                  // tile r visible; everybody is done with tile r - 1 (other buffer)
+    if (r + AHEAD < r_hi) load_k(g, r + AHEAD);
     if (active) {
-      const bf16_t* rb = base + (size_t)r * C * ld_qkv;
-      bf16x8 qf[2];
+      // the two k-halves of a key block accumulate into the same registers: keep them MAXKB MFMAs apart
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(rb + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
+      for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int kb = 0; kb < MAXKB; ++kb) {
-        const int krow = kb * 16 + fr;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kb = 0; kb < MAXKB; ++kb) {
+          const int krow = kb * 16 + fr;
           const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
-          st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+          st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, kk ? qf1 : qf0, st[kb], 0, 0, 0);
         }
       }
+    }
+  };
+  if (mode < 2) {
+    if (r_lo < r_hi) load_k(kA, r_lo);
+    if (AHEAD == 2) {
+      if (r_lo + 1 < r_hi) load_k(kB, r_lo + 1);
+      for (int r = r_lo; r < r_hi; r += 2) {
+        score_row(kA, r);
+        if (r + 1 < r_hi) score_row(kB, r + 1);
+      }
+    } else {
+      for (int r = r_lo; r < r_hi; ++r) score_row(kA, r);
     }
   }
 
@@ -112,7 +135,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
     }
     return;
   }
-  if (mode == 2 && active) {
+  if (mode == 3 && active) {
     const int qq = (q0 + fr < C) ? q0 + fr : C - 1;
     for (int c2 = 0; c2 < n_rc; ++c2) {
       const float* src = partial + (((size_t)bh * n_rc + c2) * C + qq) * tpad + fq * 4;
@@ -123,69 +146,81 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
       }
     }
   }
-  // ---- softmax over keys ---------------------------------------------------------------------
-  constexpr float LOG2E = 1.44269504088896341f;
-  float mx = -3.0e38f;
-  int tl = C - fq * 4;
-#pragma unroll
-  for (int kb = 0; kb < MAXKB; ++kb) {
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      st[kb][r4] *= scale;
-      if (kb >= MAXKB - 6 && kb * 16 + r4 >= tl) st[kb][r4] = -3.0e38f;
-      mx = fmaxf(mx, st[kb][r4]);
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  const float mneg = -mx * LOG2E;
-  float sum = 0.f;
-#pragma unroll
-  for (int kb = 0; kb < MAXKB; ++kb) {
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r4], LOG2E, mneg));
-      st[kb][r4] = e;
-      sum += e;
-    }
-  }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
-  union PF { bf16x8 v; uint32_t u[4]; };
+  union PF { bf16x8 v; uint32_t u[4]; uint4 q; };
   PF pf[MAXKB / 2];
+  // fragment store of this wave: [(bh, qblk, wave)][c][lane]
+  uint4* pfrag = (uint4*)(partial + (size_t)n_bh * n_rc * C * tpad) + (((size_t)bh * n_qblk + qblk) * NW + wave) * (MAXKB / 2) * 64 + lane;
+  if (mode == 2) {
 #pragma unroll
-  for (int c = 0; c < MAXKB / 2; ++c) {
-    const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
-    pf[c].u[0] = pack_bf16x2(lo[0] * inv, lo[1] * inv);
-    pf[c].u[1] = pack_bf16x2(lo[2] * inv, lo[3] * inv);
-    pf[c].u[2] = pack_bf16x2(hi[0] * inv, hi[1] * inv);
-    pf[c].u[3] = pack_bf16x2(hi[2] * inv, hi[3] * inv);
+    for (int c = 0; c < MAXKB / 2; ++c) pf[c].q = pfrag[c * 64];
+  } else {
+    // ---- softmax over keys ---------------------------------------------------------------------
+    constexpr float LOG2E = 1.44269504088896341f;
+    float mx = -3.0e38f;
+    int tl = C - fq * 4;
+  #pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+  #pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        st[kb][r4] *= scale;
+        if (kb >= MAXKB - 6 && kb * 16 + r4 >= tl) st[kb][r4] = -3.0e38f;
+        mx = fmaxf(mx, st[kb][r4]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mneg = -mx * LOG2E;
+    float sum = 0.f;
+  #pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+  #pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r4], LOG2E, mneg));
+        st[kb][r4] = e;
+        sum += e;
+      }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+  #pragma unroll
+    for (int c = 0; c < MAXKB / 2; ++c) {
+      const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
+      pf[c].u[0] = pack_bf16x2(lo[0] * inv, lo[1] * inv);
+      pf[c].u[1] = pack_bf16x2(lo[2] * inv, lo[3] * inv);
+      pf[c].u[2] = pack_bf16x2(hi[0] * inv, hi[1] * inv);
+      pf[c].u[3] = pack_bf16x2(hi[2] * inv, hi[3] * inv);
+    }
+    if (mode == 3) {
+#pragma unroll
+      for (int c = 0; c < MAXKB / 2; ++c) pfrag[c * 64] = pf[c].q;
+      return;
+    }
   }
 
-  // ---- pass 2: ctx[r] = P . V_r for every row (V_r^T tile prefetched the same way) ----------------
-  uint4 va[NVP], vb[NVP];
-  auto load_v = [&](int r) {
+  // ---- pass 2: ctx[r] = P . V_r for every row (V_r^T tiles: same two-buffer, two-rows-ahead scheme) ----------------
+  struct VRegs { uint4 a[NVP], b[NVP]; };
+  VRegs vA, vB;
+  auto load_v = [&](VRegs& v, int r) {
     const bf16_t* rb = base + (size_t)r * C * ld_qkv;
 #pragma unroll
     for (int it = 0; it < NVP; ++it) {
-      const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
-      va[it] = make_uint4(0, 0, 0, 0);
-      vb[it] = make_uint4(0, 0, 0, 0);
+      const int i = tid + it * NT, kp = i % hpad, cv = i / hpad;
+      v.a[it] = make_uint4(0, 0, 0, 0);
+      v.b[it] = make_uint4(0, 0, 0, 0);
       if (i < hpad * 8) {
-        if (2 * kp < C) va[it] = *(const uint4*)(rb + (size_t)(2 * kp) * ld_qkv + v_off + cv * 8);
-        if (2 * kp + 1 < C) vb[it] = *(const uint4*)(rb + (size_t)(2 * kp + 1) * ld_qkv + v_off + cv * 8);
+        if (2 * kp < C) v.a[it] = *(const uint4*)(rb + (size_t)(2 * kp) * ld_qkv + v_off + cv * 8);
+        if (2 * kp + 1 < C) v.b[it] = *(const uint4*)(rb + (size_t)(2 * kp + 1) * ld_qkv + v_off + cv * 8);
       }
     }
   };
-  if (r_lo < r_hi) load_v(r_lo);
-  for (int r = r_lo; r < r_hi; ++r) {
-    __syncthreads();
+  auto apply_row = [&](VRegs& v, int r, int slot) {
+    bf16_t* Vt = (bf16_t*)(smem + slot * BUF);
 #pragma unroll
     for (int it = 0; it < NVP; ++it) {
-      const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
+      const int i = tid + it * NT, kp = i % hpad, cv = i / hpad;
       if (i < hpad * 8) {
-        const uint32_t a[4] = {va[it].x, va[it].y, va[it].z, va[it].w}, bb[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
+        const uint32_t a[4] = {v.a[it].x, v.a[it].y, v.a[it].z, v.a[it].w}, bb[4] = {v.b[it].x, v.b[it].y, v.b[it].z, v.b[it].w};
         uint32_t* vt32 = (uint32_t*)Vt;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -193,7 +228,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
       }
     }
     __syncthreads();
-    if (r + 1 < r_hi) load_v(r + 1);
+    if (r + AHEAD < r_hi) load_v(v, r + AHEAD);
     if (active) {
       f32x4 o[4];
 #pragma unroll
@@ -221,6 +256,17 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void msa_row_attention_
         }
       }
     }
+  };
+  __syncthreads();                                    // pass 1's last tile (either buffer) fully consumed
+  if (r_lo < r_hi) load_v(vA, r_lo);
+  if (AHEAD == 2) {
+    if (r_lo + 1 < r_hi) load_v(vB, r_lo + 1);
+    for (int r = r_lo; r < r_hi; r += 2) {
+      apply_row(vA, r, 0);
+      if (r + 1 < r_hi) apply_row(vB, r + 1, 1);
+    }
+  } else {
+    for (int r = r_lo; r < r_hi; ++r) apply_row(vA, r, (r - r_lo) & 1);
   }
 }
 
@@ -228,32 +274,37 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
                                   int ld_ctx, int k_off, int v_off, float scale, float* partial, size_t partial_bytes) {
   if (B == 0 || R == 0) return 0;
   if (C <= 0) return fail(1, "row attention: empty alignment");
-  const int n_qblk = (C + 63) / 64, n_bh = B * H;
+  const int n_bh = B * H, chunks = (C + 15) / 16;
+  // workgroup width: 4 waves up to 64 columns, beyond that the widest the register
+  // budget of the score fragments allows (9 waves up to 288 keys, 8 beyond)
+  const int nw = C <= 64 ? 4 : (C <= 288 ? 9 : 8);    // must match the NW of the instantiation that serves this C
+  const int n_qblk = (chunks + nw - 1) / nw;
   // split the row loop over workgroups when the (msa, head, query-chunk) grid alone cannot fill the chip
   int n_rc = 1;
   if (partial && n_bh * n_qblk < 384 && R >= 8) {
-    n_rc = (768 + n_bh * n_qblk - 1) / (n_bh * n_qblk);
+    n_rc = 512 / (n_bh * n_qblk);                     // two whole rounds of one workgroup per CU (measured best: 512 vs 768)
     if (n_rc > R / 4) n_rc = R / 4;
     if (n_rc < 1) n_rc = 1;
   }
-  dim3 block(256);
-#define PG_ROWATT(KB)                                                                                                   \
+#define PG_ROWATT_K(KB, NWV, MODE, GRID, BLOCK)                                                                          \
+  hipLaunchKernelGGL((msa_row_attention_kernel<KB, NWV, MODE>), GRID, BLOCK, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx,     \
+                     k_off, v_off, scale, n_qblk, n_bh, n_rc, partial)
+#define PG_ROWATT(KB, NWV)                                                                                              \
   else if (C <= KB * 16) {                                                                                              \
-    if (n_rc > 1 && (size_t)n_bh * n_rc * C * (KB * 16) * 4 > partial_bytes) n_rc = 1;                                  \
+    if (n_rc > 1 && (size_t)n_bh * n_rc * C * (KB * 16) * 4 + (size_t)n_bh * n_qblk * nw * (KB / 2) * 1024 > partial_bytes) n_rc = 1; \
+    const dim3 block(NWV * 64), grid((unsigned)(n_bh * n_qblk * n_rc));                                                 \
     if (n_rc == 1) {                                                                                                    \
-      hipLaunchKernelGGL(msa_row_attention_kernel<KB>, dim3((unsigned)(n_bh * n_qblk)), block, 0, s, qkv, ctx, R, C, H,  \
-                         ld_qkv, ld_ctx, k_off, v_off, scale, n_qblk, n_bh, 0, 1, nullptr);                             \
+      PG_ROWATT_K(KB, NWV, 0, grid, block);                                                                             \
     } else {                                                                                                            \
-      const dim3 grid((unsigned)(n_bh * n_qblk * n_rc));                                                                \
-      hipLaunchKernelGGL(msa_row_attention_kernel<KB>, grid, block, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx, k_off,      \
-                         v_off, scale, n_qblk, n_bh, 1, n_rc, partial);                                                 \
-      hipLaunchKernelGGL(msa_row_attention_kernel<KB>, grid, block, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx, k_off,      \
-                         v_off, scale, n_qblk, n_bh, 2, n_rc, partial);                                                 \
+      PG_ROWATT_K(KB, NWV, 1, grid, block);                                                                             \
+      PG_ROWATT_K(KB, NWV, 3, dim3((unsigned)(n_bh * n_qblk * NWV)), dim3(64));                                         \
+      PG_ROWATT_K(KB, NWV, 2, grid, block);                                                                             \
     }                                                                                                                   \
   }
   if (false) {}
-  PG_ROWATT(2) PG_ROWATT(4) PG_ROWATT(8) PG_ROWATT(12) PG_ROWATT(18) PG_ROWATT(24) PG_ROWATT(30) PG_ROWATT(36)
+  PG_ROWATT(2, 4) PG_ROWATT(4, 4) PG_ROWATT(8, 9) PG_ROWATT(12, 9) PG_ROWATT(18, 9) PG_ROWATT(24, 8) PG_ROWATT(30, 8) PG_ROWATT(36, 8)
 #undef PG_ROWATT
+#undef PG_ROWATT_K
   else {
     return fail(5, "row attention: alignments wider than 575 columns take the fp32-scores path");
   }
