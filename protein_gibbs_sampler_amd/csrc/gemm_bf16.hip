@@ -523,9 +523,15 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
     PG_HIP(hipGetLastError());
     return 0;
   }
+  // m-panels per rasterisation group: 4, but 2 for deep K (fc2: a 256-row X panel of K = 5120 is 2.6 MB, four of them plus
+  // the W panels overflow the XCD's 4 MB L2 even slice-wise; measured 0.760 -> 0.733 ms with the bf16 epilogue)
+  static const int gm_env = [] { const char* e = getenv("PGIBBS_GEMM_GM"); return e ? atoi(e) : 0; }();
+  const int gm = gm_env ? gm_env : (K >= 4096 ? 2 : 4);
 #define PG_GEMM_CASE(E)                                                                                                   \
   case E:                                                                                                                 \
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
+    if (gm == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
+    else if (gm == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
+    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
