@@ -487,6 +487,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 //   * 1 or 2 of the 4 DMA pieces issued inside the MFMA segment: -1 % / -2 %;
 //   * half of the first round's workgroups started half a tile late (to de-phase the chip-wide store bursts): 0 ... -2 %;
 //   * peeling the partial last round of tiles into a 128x128 launch: no gain (the dispatcher back-fills);
+//   * a "W-stationary" tile order (4-5 n-tiles at a time over a band of 32 m-panels, so their W panels stay in the XCD's
+//     L2 while X streams): 0 ... -2 % on all four shapes, although making EVERY DMA hit in L2 (ablation 17) is worth 14 %;
 //   * touching the residual tile's cache lines at the start of the main loop (so that the read half of the epilogue's
 //     read-modify-write is spread out): out-proj 0.31 -> 0.35 ms;
 //   * a persistent kernel (one workgroup per CU; after a tile, waves 0-3 store it from 64 KB of LDS staging while waves
