@@ -198,7 +198,8 @@ int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t*
  * 2 residual (out is read too: out += x w^T + bias), 3 bf16 output, 4 bf16 output + gelu */
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi);
-/* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events); variant 1 =
+/* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events; M a multiple of 16,
+ * of 64 above 256); variant 1 =
  * lockstep kernel, 2 = ping-pong kernel; epi: 0 bf16 out, 1 bf16+gelu, 2 fp32 residual, 3 fp32, 4 fp32+gelu */
 int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int iters, double* avg_ms);
 /* y = LayerNorm(x[M][d]) * gamma + beta */

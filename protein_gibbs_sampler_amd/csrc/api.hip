@@ -398,16 +398,16 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
 }
 
 int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int iters, double* avg_ms) {
-  if (!avg_ms || M % 256 || N % 128 || K % 64 || iters < 1) return fail(PG_ERR_INVALID, "pg_dbg_gemm_bench: bad argument");
+  if (!avg_ms || M % 16 || (M > 256 && M % 64) || N % 64 || K % 64 || iters < 1) return fail(PG_ERR_INVALID, "pg_dbg_gemm_bench: bad argument");
   DeviceGuard g(-1);
   int rc = dbg_device(device);
   if (rc) return rc;
   Tmp t;
   float* f = (float*)t.get((size_t)(M > N ? M : N) * K * 4);
-  bf16_t* bx = (bf16_t*)t.get((size_t)M * K * 2);
+  bf16_t* bx = (bf16_t*)t.get((size_t)round_up(M, kRowPad) * K * 2);   // kernels may touch the padding rows of the last tile
   bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2);
   float* db = (float*)t.get((size_t)N * 4);
-  void* dout = t.get((size_t)M * N * 4);
+  void* dout = t.get((size_t)round_up(M, kRowPad) * N * 4);
   if (!f || !bx || !bw || !db || !dout) return fail(PG_ERR_HIP, "hipMalloc failed");
   std::vector<float> h((size_t)(M > N ? M : N) * K);
   uint32_t st = 12345u;

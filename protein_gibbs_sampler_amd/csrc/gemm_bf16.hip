@@ -698,22 +698,37 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant) {
-  if (M >= 16 && M <= 256 && M % 16 == 0 && N % 16 == 0 && K % 64 == 0 && variant != 1) {
-    // rows beyond M inside the last m-tile group are read/written too: callers pad buffers to 256 rows
+  // Dispatch by how many tiles each kernel would put on the 256 CUs (times in us, tools/gemm_mid_bench.py, N=1280 K=1280):
+  //   M =    16    64   256  1024  4096  16384
+  //   skinny 4.3   8.7  26.4                       one workgroup per 16 output features, weights streamed once
+  //   64^2         7.7   7.9  13.6  31.7           5 workgroups per CU: fills the chip from 64 token rows on
+  //   128^2             16.4  19.8  26.9   78
+  //   256^2 ping-pong         31.4  36.4   87      (wins from >= 128 tiles: 41 vs 49 us at M = 8192)
+  if (K % 64) return fail(1, "gemm: K must be a multiple of 64");
+  if (variant == 6 && M % 64 == 0 && N % 64 == 0) return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  if (variant == 7 && M % 128 == 0 && N % 128 == 0) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  if (M >= 16 && M <= 48 && M % 16 == 0 && N % 16 == 0 && variant != 1) {
     const int mt = M / 16;
     if (mt <= 1) return launch_skinny_mt<1>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
     if (mt <= 2) return launch_skinny_mt<2>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
-    if (mt <= 4) return launch_skinny_mt<4>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
-    if (mt <= 8) return launch_skinny_mt<8>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
-    return launch_skinny_mt<16>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
+    return launch_skinny_mt<4>(s, X, W, bias, out, N, K, ldx, ldw, ldo, epi);
   }
-  if (M % 128 || N % 128 || K % 64) return fail(1, "gemm: M,N must be multiples of 128 and K of 64");
-  if (M % 256 == 0 && N % 256 == 0 && K >= 128 && variant >= 20) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
-  // (Peeling the 1-3 % full last round of tiles into a trailing 128x128 launch was measured: no gain -- blocks do not
-  //  run in lockstep rounds, the dispatcher back-fills -- so every 256-multiple shape goes to one launch.)
-  if (M % 256 == 0 && N % 256 == 0 && K >= 128 && variant >= 2) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
-  if (M % 256 == 0 && N % 256 == 0) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
-  return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  if (M <= 256) {
+    // rows beyond M inside the last 64-row tile are read/written too: callers pad buffers to 256 rows
+    if (M % 16 || N % 64) return fail(1, "gemm: M must be a multiple of 16 and N of 64");
+    return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, (M + 63) / 64 * 64, N, K, ldx, ldw, ldo, epi);
+  }
+  if (M % 128 || N % 64) return fail(1, "gemm: M must be a multiple of 128 and N of 64");
+  const bool ok256 = M % 256 == 0 && N % 256 == 0 && K >= 128, ok128 = N % 128 == 0;
+  const long t256 = (long)(M / 256) * (N / 256), t128 = (long)(M / 128) * (N / 128);
+  if (variant >= 20 && ok256) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
+  if (variant == 1) {
+    if (ok256) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+    if (ok128) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  }
+  if (ok256 && t256 >= 128) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  if (ok128 && (t128 >= 200 || !(M % 64 == 0))) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }
 
 }  // namespace pg
