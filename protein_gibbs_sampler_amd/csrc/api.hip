@@ -388,9 +388,12 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
     if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, bout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
                                epi == 4 ? EPI_BF16_GELU : EPI_BF16))) return rc;
     if ((rc = launch_bf16_to_f32(nullptr, bout, dout, (int64_t)M * N))) return rc;
-  } else if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
-                                    epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32)))) {
-    return rc;
+  } else {
+    // the residual variant gets split-K scratch, as the engine gives its fc2 GEMMs (taken for deep K and few tiles)
+    const size_t ws_bytes = epi == 2 ? (size_t)5 * Mp * N * 4 : 0;
+    float* ws = ws_bytes && ws_bytes <= ((size_t)1 << 30) ? (float*)t.get(ws_bytes) : nullptr;
+    if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
+                               epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32), ws, ws ? ws_bytes : 0))) return rc;
   }
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -409,6 +412,8 @@ int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int
   float* db = (float*)t.get((size_t)N * 4);
   void* dout = t.get((size_t)round_up(M, kRowPad) * N * 4);
   if (!f || !bx || !bw || !db || !dout) return fail(PG_ERR_HIP, "hipMalloc failed");
+  const size_t ws_bytes = (epi == EPI_F32_RESID && M <= 8192) ? (size_t)5 * round_up(M, kRowPad) * N * 4 : 0;
+  float* ws = ws_bytes ? (float*)t.get(ws_bytes) : nullptr;
   std::vector<float> h((size_t)(M > N ? M : N) * K);
   uint32_t st = 12345u;
   for (auto& v : h) { st = st * 1664525u + 1013904223u; v = ((st >> 8) * (1.0f / 8388608.0f) - 1.0f); }   // uniform [-1,1)
@@ -419,10 +424,10 @@ int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int
   PG_HIP(hipEventCreate(&a));
   PG_HIP(hipEventCreate(&b));
   for (int i = 0; i < 2; ++i)
-    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant))) return rc;
+    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant, ws, ws ? ws_bytes : 0))) return rc;
   PG_HIP(hipEventRecord(a, nullptr));
   for (int i = 0; i < iters; ++i)
-    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant))) return rc;
+    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant, ws, ws ? ws_bytes : 0))) return rc;
   PG_HIP(hipEventRecord(b, nullptr));
   PG_HIP(hipEventSynchronize(b));
   float ms = 0;

@@ -77,8 +77,13 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ src, int l
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const float* __restrict__ bias, void* __restrict__ out,
-    int K, int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+    int K, int ldx, int ldw, int ldo, int tiles_n, int n_tiles, long split_stride) {
   constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN;
+  if (EPI == EPI_F32_PARTIAL) {                    // K-split blockIdx.y: its K range of both operands, its partial map
+    X += (size_t)blockIdx.y * K;
+    W += (size_t)blockIdx.y * K;
+    out = (float*)out + (size_t)blockIdx.y * split_stride;
+  }
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int TILE_BYTES = (BM + BN) * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
@@ -143,7 +148,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int n = n0 + wn * WN + i * 16 + fq * 4;
-    const float4 b4 = *(const float4*)(bias + n);
+    const float4 b4 = EPI == EPI_F32_PARTIAL ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(bias + n);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = m0 + wm * WM + j * 16 + fr;
@@ -559,7 +564,12 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 template <int MT, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                              int ldx, int ldw, int ldo) {
+                                                              int ldx, int ldw, int ldo, long split_stride) {
+  if (EPI == EPI_F32_PARTIAL) {
+    X += (size_t)blockIdx.y * K;
+    W += (size_t)blockIdx.y * K;
+    out = (float*)out + (size_t)blockIdx.y * split_stride;
+  }
   __shared__ float red[NW - 1][MT][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
   __syncthreads();
   if (wave > 0) return;
   // lane holds D[n = n0 + fq*4 + r][m = t*16 + fr]
-  const float4 b4 = *(const float4*)(bias + n0 + fq * 4);
+  const float4 b4 = EPI == EPI_F32_PARTIAL ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(bias + n0 + fq * 4);
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     f32x4 v = acc[t];
@@ -642,15 +652,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
 
 template <int MT>
 static int launch_skinny_mt(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int N, int K, int ldx,
-                            int ldw, int ldo, int epi) {
+                            int ldw, int ldo, int epi, int splits = 1, long split_stride = 0) {
   // 8 waves per workgroup (K split 8 ways: twice the loads in flight per CU) whenever each wave still gets whole
   // 32-wide k-steps and the m-tile count keeps the register footprint small
   const bool w8 = (K % 256 == 0) && MT <= 4;
-  dim3 grid(N / 16), block(w8 ? 512 : 256);
+  dim3 grid(N / 16, splits), block(w8 ? 512 : 256);
 #define PG_GEMM_CASE(E)                                                                                              \
   case E:                                                                                                            \
-    if (w8) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, E, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo); \
-    else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, E, 4>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo);    \
+    if (w8) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, E, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, split_stride); \
+    else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, E, 4>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, split_stride);    \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
@@ -658,6 +668,7 @@ static int launch_skinny_mt(hipStream_t s, const bf16_t* X, const bf16_t* W, con
     PG_GEMM_CASE(EPI_F32_RESID)
     PG_GEMM_CASE(EPI_F32)
     PG_GEMM_CASE(EPI_F32_GELU)
+    PG_GEMM_CASE(EPI_F32_PARTIAL)
     default:
       return fail(1, "gemm: bad epilogue");
   }
@@ -668,13 +679,13 @@ static int launch_skinny_mt(hipStream_t s, const bf16_t* X, const bf16_t* W, con
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
-                      int K, int ldx, int ldw, int ldo, int epi) {
+                      int K, int ldx, int ldw, int ldo, int epi, int splits = 1, long split_stride = 0) {
   const int tiles_m = M / BM, tiles_n = N / BN, n_tiles = tiles_m * tiles_n;
-  dim3 grid(n_tiles), block((BM / WM) * (BN / WN) * 64);
+  dim3 grid(n_tiles, splits), block((BM / WM) * (BN / WN) * 64);
 #define PG_GEMM_CASE(E)                                                                                              \
   case E:                                                                                                            \
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, \
-                       tiles_n, n_tiles);                                                                   \
+                       tiles_n, n_tiles, split_stride);                                                     \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
@@ -682,6 +693,7 @@ static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const flo
     PG_GEMM_CASE(EPI_F32_RESID)
     PG_GEMM_CASE(EPI_F32)
     PG_GEMM_CASE(EPI_F32_GELU)
+    PG_GEMM_CASE(EPI_F32_PARTIAL)
     default:
       return fail(1, "gemm: bad epilogue");
   }
@@ -690,14 +702,32 @@ static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const flo
   return 0;
 }
 
+// out[m][n] += bias[n] + sum over the K-splits, in split order (fixed -> bit-reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int n4, int ldo, long total4, int splits,
+                                                           long split_stride) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int m = (int)(i / n4), c = (int)(i - (long)m * n4);
+  float4 a = *(const float4*)(bias + c * 4);
+  for (int sidx = 0; sidx < splits; ++sidx) {
+    const float4 p = *(const float4*)(part + (size_t)sidx * split_stride + (size_t)i * 4);
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+  }
+  float4* o = (float4*)(out + (size_t)m * ldo + c * 4);
+  float4 r = *o;
+  r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+  *o = r;
+}
+
 int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi) {
+                     int ldx, int ldw, int ldo, int epi, float* ws, size_t ws_bytes) {
   static const int variant = [] { const char* e = getenv("PGIBBS_GEMM"); return e ? atoi(e) : 2; }();
-  return launch_gemm_bf16_variant(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant);
+  return launch_gemm_bf16_variant(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant, ws, ws_bytes);
 }
 
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
-                             int K, int ldx, int ldw, int ldo, int epi, int variant) {
+                             int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws, size_t ws_bytes) {
   // Dispatch by how many tiles each kernel would put on the 256 CUs (times in us, tools/gemm_mid_bench.py, N=1280 K=1280):
   //   M =    16    64   256  1024  4096  16384
   //   skinny 4.3   8.7  26.4                       one workgroup per 16 output features, weights streamed once
@@ -705,6 +735,34 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   //   128^2             16.4  19.8  26.9   78
   //   256^2 ping-pong         31.4  36.4   87      (wins from >= 128 tiles: 41 vs 49 us at M = 8192)
   if (K % 64) return fail(1, "gemm: K must be a multiple of 64");
+  // Deep K with few tiles (fc2 of a few dozen chains: K = 5120, 80-320 tiles): K-splits run side by side into ws, then one
+  // reduction adds them to the residual stream in fixed order.  M = 1024: 43 -> 21 us, M = 32: 15.6 -> 8 us.
+  if (epi == EPI_F32_RESID && ws && K >= 2048 && M >= 16 && M % 16 == 0 && N % 64 == 0 && variant != 1 && variant < 6) {
+    const int splits = K % 1280 == 0 ? K / 1280 : (K % 1024 == 0 ? K / 1024 : 1);
+    const int Mr = M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 256 ? (M + 63) / 64 * 64 : M));   // rows the kernels write (their tile heights)
+    const long t64 = (long)(Mr / 64) * (N / 64);
+    const bool pp_sized = M % 256 == 0 && N % 256 == 0 && (long)(M / 256) * (N / 256) >= 128;   // the 256^2 kernel fills the chip
+    const bool small = M <= 48 || ((M <= 256 || M % 64 == 0) && t64 * splits <= 1280 && !pp_sized);
+    const long stride = (long)Mr * N;
+    if (splits > 1 && small && (size_t)splits * stride * 4 <= ws_bytes && (K / splits) % 64 == 0) {
+      int rc;
+      const int Ks = K / splits;
+      if (M <= 48) {
+        const int mt = M / 16;
+        rc = mt <= 1 ? launch_skinny_mt<1>(s, X, W, bias, ws, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride)
+           : mt <= 2 ? launch_skinny_mt<2>(s, X, W, bias, ws, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride)
+                     : launch_skinny_mt<4>(s, X, W, bias, ws, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride);
+      } else {
+        rc = launch_cfg<64, 64, 32, 32>(s, X, W, bias, ws, Mr, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride);
+      }
+      if (rc) return rc;
+      const long total4 = stride / 4;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, ws, bias, (float*)out, N / 4,
+                         ldo, total4, splits, stride);
+      PG_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   if (variant == 6 && M % 64 == 0 && N % 64 == 0) return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (variant == 7 && M % 128 == 0 && N % 128 == 0) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (M >= 16 && M <= 48 && M % 16 == 0 && N % 16 == 0 && variant != 1) {

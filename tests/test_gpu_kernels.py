@@ -29,6 +29,8 @@ def _gelu(x):
                                        # epi 2 = residual read-modify-write (out += x w^T + b): 256^2, 128^2 and skinny kernels
                                        (513, 1280, 1280, 2), (700, 1280, 320, 2), (300, 384, 256, 2), (40, 1280, 5120, 2),
                                        (512, 1280, 320, 0), (512, 1280, 320, 1), (300, 256, 64, 2),
+                                       # deep K, few tiles: split-K into scratch + fixed-order reduction (skinny, 64^2; K = 4*1280, 3*1024)
+                                       (32, 1280, 5120, 2), (216, 1280, 5120, 2), (1000, 768, 3072, 2), (2048, 1280, 5120, 2), (48, 256, 2048, 2),
                                        # epi 3 / 4 = bf16 outputs (QKV / fc1 epilogues): one-shot 256^2, 128^2, skinny ...
                                        (513, 1280, 1280, 3), (700, 1280, 320, 4), (300, 384, 256, 3), (40, 1280, 5120, 4),
                                        # ... and >= 2 tiles per CU: the persistent kernel (ragged XCD shares, odd K-tile count)
