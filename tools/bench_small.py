@@ -11,7 +11,7 @@ with warnings.catch_warnings():
 seed = "MEPAATGQEAEECAHSGRGEAWEEV"
 kw = dict(batch_size=1, num_iters=20, burnin=10, mask=True, in_order=False, num_positions_percent=10, top_k=1, show_progress_bar=False)
 random.seed(0); s.generate(1, seed, **kw)
-for B in (1, 8, 32):
+for B in [int(b) for b in os.environ.get("PGIBBS_SMALL_B", "1,8,32").split(",")]:
     kw["batch_size"] = B
     s.generate(B, seed, **kw)
     t0 = time.perf_counter()
