@@ -141,6 +141,33 @@ def test_graph_replay_matches_eager_loop():
     assert again == outs[0]
 
 
+def test_deep_ffn_takes_split_k_path():
+    """d_ffn >= 2048 with few token rows: fc2 runs as parallel K-splits + one fixed-order reduction (weight-streaming kernel
+    for a single chain, 64x64 tiles for a small batch).  Logits against the oracle, run-to-run bit equality, and the
+    graph-replayed Gibbs loop against the eager one."""
+    ck = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=2048, max_pos=80)
+    ocfg = EsmConfig(**ck)
+    sd = synthetic_esm_weights(ocfg, seed=41, std=0.05, embed_std=0.5, ln_jitter=0.1)
+    model = _model(ck, sd)
+    m = model.model.to("cuda:0")
+    rng = np.random.default_rng(7)
+    for B, T in ((1, 27), (20, 60)):
+        tok = rng.integers(4, 24, (B, T))
+        tok[:, 0], tok[:, -1] = 0, 2
+        tok[0, 3:6] = 32
+        got = m.forward_logits(tok)
+        assert np.abs(got - esm1b_forward(sd, ocfg, tok)).max() < BF16_TOL
+        assert (got == m.forward_logits(tok)).all()
+    s = esm_sampler.ESM_sampler(model, device="cuda:0")
+    outs = []
+    for record in (False, True):
+        s.draw_seed, s.record = 3, record
+        random.seed(4)
+        outs.append(s.generate(4, "MEPAATGQEAEECAHSGRGEAWEEV", batch_size=2, num_iters=5, num_positions=4, top_k=1, burnin=2,
+                               show_progress_bar=False))
+    assert outs[0] == outs[1]
+
+
 def test_engine_rejects_bad_weights_and_shapes():
     ck = dict(d_model=128, n_layers=1, n_heads=2, d_ffn=256, max_pos=40)
     sd = synthetic_esm_weights(EsmConfig(**ck), seed=1)
