@@ -494,6 +494,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 //   * peeling the partial last round of tiles into a 128x128 launch: no gain (the dispatcher back-fills);
 //   * a "W-stationary" tile order (4-5 n-tiles at a time over a band of 32 m-panels, so their W panels stay in the XCD's
 //     L2 while X streams): 0 ... -2 % on all four shapes, although making EVERY DMA hit in L2 (ablation 17) is worth 14 %;
+//   * direct 16-B stores from the accumulators (16 rows x 64-B segments per instruction, possible with a permuted W-row
+//     to fragment assignment) instead of the LDS-staged 512-B rows: timing-only ablation 0.582 vs 0.573 ms;
 //   * touching the residual tile's cache lines at the start of the main loop (so that the read half of the epilogue's
 //     read-modify-write is spread out): out-proj 0.31 -> 0.35 ms;
 //   * a persistent kernel (one workgroup per CU; after a tile, waves 0-3 store it from 64 KB of LDS staging while waves
