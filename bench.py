@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--chains-per-gpu", type=int, default=256)
     ap.add_argument("--length", type=int, default=256)
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the JSON then says so)")
+    ap.add_argument("--greedy-after-burnin", action="store_true",
+                    help="SURVEY 8d variant: top_k=1, burnin=25 (argmax after 25 sampled iterations) instead of all-sampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -147,7 +149,8 @@ def main():
     pos_rng = pyrandom.NativePyRandom()
     pos_rng.seed(0)
     population = list(range(1, L + 1))
-    params = _lib.make_sample_params(True, cfg["mask_idx"], 0, float("inf"), 1.0, valid_idx, rng_seed=0, rng_stream=0,
+    top_k, burnin = (1, 25.0) if args.greedy_after_burnin else (0, float("inf"))
+    params = _lib.make_sample_params(True, cfg["mask_idx"], top_k, burnin, 1.0, valid_idx, rng_seed=0, rng_stream=0,
                                      row_id_base=rank * B)
     stream = torch.cuda.current_stream(dev)
     _lib.check(L_.pg_engine_set_stream(lm.handle, ctypes.c_void_p(stream.cuda_stream)))
@@ -188,8 +191,9 @@ def main():
            "unit": "sampled positions/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "ESM_sampler ESM-1b (33 layers, d=1280) Gibbs: %d chains/GPU x L=%d (T=%d), P=%d positions "
-                                  "per chain per iteration, mask=True top_k=0 temperature=1.0 burnin=inf; bf16 MFMA "
-                                  "operands, fp32 accumulate + fp32 residual stream; synthetic N(0,0.02) weights" % (B, L, T, P),
+                                  "per chain per iteration, mask=True top_k=%d temperature=1.0 burnin=%s; bf16 MFMA "
+                                  "operands, fp32 accumulate + fp32 residual stream; synthetic N(0,0.02) weights"
+                                  % (B, L, T, P, top_k, "inf" if burnin == float("inf") else int(burnin)),
                       "global_batch": B_total, "seq_len": L, "parallelism": "chains sharded %d-way, 1 RCCL all-gather at end" % world,
                       "n_layers": cfg["n_layers"]}}
 
