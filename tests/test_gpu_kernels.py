@@ -31,6 +31,8 @@ def _gelu(x):
                                        (512, 1280, 320, 0), (512, 1280, 320, 1), (300, 256, 64, 2),
                                        # deep K, few tiles: split-K into scratch + fixed-order reduction (skinny, 64^2; K = 4*1280, 3*1024)
                                        (32, 1280, 5120, 2), (216, 1280, 5120, 2), (1000, 768, 3072, 2), (2048, 1280, 5120, 2), (48, 256, 2048, 2),
+                                       # 128x128-tile kernel (>= 200 of its tiles, < 128 tiles of 256^2)
+                                       (2048, 2304, 128, 2), (2048, 2304, 192, 4), (2304, 1792, 64, 0),
                                        # epi 3 / 4 = bf16 outputs (QKV / fc1 epilogues): one-shot 256^2, 128^2, skinny ...
                                        (513, 1280, 1280, 3), (700, 1280, 320, 4), (300, 384, 256, 3), (40, 1280, 5120, 4),
                                        # ... and >= 2 tiles per CU: the persistent kernel (ragged XCD shares, odd K-tile count)
