@@ -89,7 +89,11 @@ int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, flo
   if ((rc = e.d_tokens.ensure((size_t)M * 4, e.stream))) return rc;
   if ((rc = e.logits.ensure((size_t)M * e.cfg.vocab * 4, e.stream))) return rc;
   PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens, (size_t)M * 4, hipMemcpyHostToDevice, e.stream));
-  if ((rc = e.esm_trunk(e.d_tokens.as<int32_t>(), B, T))) return rc;
+  e.esm_pad_in_batch = false;                       // ragged batch: <pad> keys are masked in attention (fair-esm key_padding_mask)
+  for (int64_t i = 0; i < M; ++i) e.esm_pad_in_batch |= tokens[i] == e.cfg.pad_idx;
+  rc = e.esm_trunk(e.d_tokens.as<int32_t>(), B, T);
+  e.esm_pad_in_batch = false;
+  if (rc) return rc;
   if ((rc = e.head(nullptr, nullptr, 1, T, M, e.logits.as<float>()))) return rc;
   PG_HIP(hipMemcpyAsync(logits_out, e.logits.p, (size_t)M * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
@@ -250,7 +254,12 @@ static int forward_logprobs(Engine& e, bool msa, const int32_t* tokens, int B, i
   PG_HIP(hipMemcpyAsync(e.d_idx.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, e.stream));
   PG_HIP(hipMemcpyAsync(e.d_samp_tok.p, targets, (size_t)n * 4, hipMemcpyHostToDevice, e.stream));
   PG_HIP(hipMemcpyAsync(e.d_rowmap.p, row_of, (size_t)n_sel * 4, hipMemcpyHostToDevice, e.stream));
-  if ((rc = msa ? e.msa_trunk(e.d_tokens.as<int32_t>(), B, R, C) : e.esm_trunk(e.d_tokens.as<int32_t>(), B, C))) return rc;
+  e.esm_pad_in_batch = false;
+  if (!msa)
+    for (int64_t i = 0; i < M; ++i) e.esm_pad_in_batch |= tokens[i] == e.cfg.pad_idx;
+  rc = msa ? e.msa_trunk(e.d_tokens.as<int32_t>(), B, R, C) : e.esm_trunk(e.d_tokens.as<int32_t>(), B, C);
+  e.esm_pad_in_batch = false;
+  if (rc) return rc;
   if ((rc = e.head(e.d_idx.as<int32_t>(), e.d_rowmap.as<int32_t>(), P, C, n, e.logits.as<float>()))) return rc;
   if ((rc = launch_logprob_gather(e.stream, e.logits.as<float>(), e.cfg.vocab, 1, C, e.d_idx.as<int32_t>(), e.d_rowmap.as<int32_t>(),
                                   e.d_samp_tok.as<int32_t>(), n_sel, P, e.d_samp_logits.as<float>()))) return rc;

@@ -27,7 +27,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 template <int MAXKB>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
-                                                       SeqLayout sl) {
+                                                       SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx) {
   constexpr int VT_LD = MAXKB * 16 + 8;  // bf16 elements per V^T row (592 B at MAXKB=18: conflict-free b64 reads)
   __shared__ __attribute__((aligned(16))) char smem[MAXKB * 16 * 128 + 64 * VT_LD * 2];
   char* Ks = smem;
@@ -151,6 +151,21 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         mx = fmaxf(mx, st[kb][r]);
       }
     }
+    if (key_tok) {
+      // ragged batch (only reachable through the forward entry points; the Gibbs path never holds <pad>): keys that are
+      // <pad> tokens get -inf like fair-esm's key_padding_mask.  key_tok = the token buffer, sequence `seq` at seq*T.
+      const int32_t* kt = key_tok + (size_t)seq * T;
+      mx = -3.0e38f;
+#pragma unroll
+      for (int kb = 0; kb < MAXKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * 16 + fq * 4 + r;
+          if (key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
+          mx = fmaxf(mx, st[kb][r]);
+        }
+      }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mneg = -mx * 1.44269504088896341f;
@@ -226,7 +241,8 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                                int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
-                                                               SeqLayout sl, int n_qchunk) {
+                                                               SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok,
+                                                               int pad_idx) {
   constexpr int MAXKB = 18, tpad = MAXKB * 16, nkc = MAXKB / 2, VT_LD = tpad + 8;
   __shared__ __attribute__((aligned(16))) char smem[tpad * 128 + 64 * VT_LD * 2];
   char* Ks = smem;
@@ -313,6 +329,18 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
         if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
         tmax = fmaxf(tmax, st[kb][r]);
       }
+    if (key_tok) {                               // <pad> keys of a ragged batch (see attention_kernel)
+      const int32_t* kt = key_tok + (size_t)seq * T + k0;
+      tmax = -3.0e38f;
+#pragma unroll
+      for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * 16 + fq * 4 + r;
+          if (k0 + key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
+          tmax = fmaxf(tmax, st[kb][r]);
+        }
+    }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float mn = fmaxf(m, tmax);
@@ -368,19 +396,19 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
 }
 
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
-                          int k_off, int v_off) {
+                          int k_off, int v_off, const int32_t* key_tok, int pad_idx) {
   SeqLayout sl = {1, T, 0, 1};
-  return launch_attention_seq_bf16(s, qkv, ctx, B, T, H, ld_qkv, ld_ctx, k_off, v_off, sl);
+  return launch_attention_seq_bf16(s, qkv, ctx, B, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx);
 }
 
 int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int64_t n_seq, int T, int H, int ld_qkv,
-                              int ld_ctx, int k_off, int v_off, SeqLayout sl) {
+                              int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx) {
   if (n_seq == 0) return 0;
   if (n_seq * H > 0x7fffffff) return fail(1, "attention: too many sequences");
   dim3 grid((unsigned)(n_seq * H)), block(256);
 #define PG_ATT(KB)                                                                                             \
   else if (T <= KB * 16) {                                                                                     \
-    hipLaunchKernelGGL(attention_kernel<KB>, grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl); \
+    hipLaunchKernelGGL(attention_kernel<KB>, grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx); \
   }
   if (T <= 0) return fail(1, "attention: empty sequence");
   PG_ATT(2) PG_ATT(4) PG_ATT(8) PG_ATT(12) PG_ATT(18) PG_ATT(24) PG_ATT(30) PG_ATT(36)
@@ -389,7 +417,7 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
     const int n_qchunk = (T + 63) / 64;
     if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
     hipLaunchKernelGGL(attention_long_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), block, 0, s, qkv, ctx, T, H, ld_qkv,
-                       ld_ctx, k_off, v_off, sl, n_qchunk);
+                       ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx);
   }
   PG_HIP(hipGetLastError());
   return 0;

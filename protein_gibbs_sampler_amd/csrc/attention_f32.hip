@@ -9,7 +9,8 @@ namespace pg {
 
 __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ ctx_hi,
                                                           bf16_t* __restrict__ ctx_lo, int T, int H, int ld_qkv_,
-                                                          int ld_ctx_, int k_off, int v_off, SeqLayout sl, int n_qchunk) {
+                                                          int ld_ctx_, int k_off, int v_off, SeqLayout sl, int n_qchunk,
+                                                          const int32_t* __restrict__ key_tok, int pad_idx) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * 64];
   __shared__ __attribute__((aligned(16))) float Vs[64 * 64];
   const int lane = threadIdx.x;
@@ -60,7 +61,9 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
         acc = fmaf(q[4 * c + 2], kv.z, acc);
         acc = fmaf(q[4 * c + 3], kv.w, acc);
       }
-      s[key] = key < nk ? acc : -3.0e38f;
+      // keys beyond T, and <pad> keys of a ragged batch (key_tok = token buffer, sequence seq at seq*T)
+      const bool masked = key >= nk || (key_tok && key_tok[(size_t)seq * T + k0 + key] == pad_idx);
+      s[key] = masked ? -3.0e38f : acc;
       tmax = fmaxf(tmax, s[key]);
     }
     const float mn = fmaxf(m, tmax);
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
     for (int i = 0; i < 64; ++i) o[i] *= alpha;
 #pragma unroll
     for (int key = 0; key < 64; ++key) {
-      const float p = key < nk ? expf(s[key] - mn) : 0.f;
+      const float p = s[key] > -1.0e38f ? expf(s[key] - mn) : 0.f;
       l += p;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -224,13 +227,13 @@ int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores,
 }
 
 int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx_hi, bf16_t* ctx_lo, int64_t n_seq, int T, int H,
-                         int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl) {
+                         int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx) {
   if (n_seq == 0) return 0;
   if (T <= 0) return fail(1, "attention: empty sequence");
   const int n_qchunk = (T + 63) / 64;
   if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
   hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), dim3(64), 0, s, qkv, ctx_hi, ctx_lo, T, H,
-                     ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk);
+                     ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx);
   PG_HIP(hipGetLastError());
   return 0;
 }

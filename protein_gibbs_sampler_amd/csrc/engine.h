@@ -67,6 +67,7 @@ struct Engine {
   // strict precision mode (PG_PREC_FP32): lo halves of the split-bf16 operands, fp32 GEMM outputs, row-attention scores
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
+  bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask
   float* splitk_ws(int rows, int n);
   // launch-bound (small) Gibbs loops: one iteration captured as a hipGraph and replayed; the iteration number lives in
   // d_iter on the device, so the same graph serves every iteration

@@ -282,7 +282,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       const EsmLayer& L = esm_layers[l];
       if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, h_lo.as<bf16_t>()); }))) return rc;
       if ((rc = dense3(h.as<bf16_t>(), h_lo.as<bf16_t>(), L.qkv, QKVf, Mi, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), ctx_lo.as<bf16_t>(), B, T, cfg.n_heads, 3 * d, d, d, 2 * d, chain); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), ctx_lo.as<bf16_t>(), B, T, cfg.n_heads, 3 * d, d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
       if ((rc = dense3(ctx.as<bf16_t>(), ctx_lo.as<bf16_t>(), L.out, X, Mi, true))) return rc;
       if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, h_lo.as<bf16_t>()); }))) return rc;
       if ((rc = dense3(h.as<bf16_t>(), h_lo.as<bf16_t>(), L.fc1, ffn_f32.as<float>(), Mi, false))) return rc;
@@ -313,7 +313,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     const EsmLayer& L = esm_layers[l];
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
-    if ((rc = timed(PC_ATTN, [&] { return launch_attention_bf16(stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return launch_attention_bf16(stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: only the selected rows are ever read again -> gather them and finish the layer on n_sel rows
       const int64_t Np = round_up64(n_sel, kRowPad);

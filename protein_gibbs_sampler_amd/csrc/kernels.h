@@ -23,10 +23,12 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
                              int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws = nullptr, size_t ws_bytes = 0);
 
 // fused attention, one (sequence, head) per workgroup; qkv rows are [q | k | v] with head h at h*64
+// key_tok (optional): the int32 token buffer [n_seq][T]; keys whose token is pad_idx are masked (ragged batches)
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
-                          int k_off, int v_off);
+                          int k_off, int v_off, const int32_t* key_tok = nullptr, int pad_idx = -1);
 int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int64_t n_seq, int T, int H, int ld_qkv,
-                              int ld_ctx, int k_off, int v_off, SeqLayout sl);
+                              int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok = nullptr,
+                              int pad_idx = -1);
 // MSA tied row attention: one C x C map per (msa, head) from scores summed over the R rows
 // `partial` (optional fp32 scratch of partial_bytes) enables the split-R mode used when B*H is small
 int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
@@ -48,7 +50,8 @@ int launch_split_bf16(hipStream_t s, const float* src, bf16_t* hi, bf16_t* lo, i
 int launch_gelu_f32(hipStream_t s, float* p, int64_t n);
 // strict precision mode attention: fp32 qkv in, softmax and accumulation in fp32 (VALU), ctx out as a (hi, lo) pair
 int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx_hi, bf16_t* ctx_lo, int64_t n_seq, int T, int H,
-                         int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl);
+                         int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok = nullptr,
+                         int pad_idx = -1);
 // strict tied row attention; `scores` is an fp32 scratch of B*H*C*C floats
 int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx_hi, bf16_t* ctx_lo, int B, int R,
                                  int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale);

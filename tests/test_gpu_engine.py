@@ -141,6 +141,33 @@ def test_graph_replay_matches_eager_loop():
     assert again == outs[0]
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16", BF16_TOL), ("fp32", STRICT_TOL)])
+def test_padded_ragged_batch_forward(precision, tol):
+    """A right-padded ragged batch, as the reference's log_likelihood_batch hands to `model.model(batch)`
+    (esm_sampler.py:340,355): <pad> keys are masked in attention, <pad> rows are zeroed after the embedding LayerNorm and do
+    not count in the token-dropout rescale -- logits at the real positions must equal the oracle's (fair-esm semantics)."""
+    ck = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=700)
+    ocfg = EsmConfig(**ck)
+    sd = synthetic_esm_weights(ocfg, seed=51, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    m = _model(ck, sd, precision=precision).model.to("cuda:0")
+    rng = np.random.default_rng(11)
+    for T, lens in ((40, (38, 17, 5, 29)), (620, (618, 100))):        # whole-sequence kernel / long-sequence kernel
+        tok = np.full((len(lens), T), 1, dtype=np.int64)               # <pad> = 1
+        for b, n in enumerate(lens):
+            tok[b, 0] = 0
+            tok[b, 1:n + 1] = rng.integers(4, 24, n)
+            tok[b, n + 1] = 2
+            tok[b, 3] = 32
+        got = m.forward_logits(tok)
+        want = esm1b_forward(sd, ocfg, tok)
+        real = tok != 1
+        assert np.abs(got[real] - want[real]).max() < tol
+        # and the unpadded sequence alone gives the same logits (padding must be invisible)
+        n = lens[1]
+        alone = m.forward_logits(tok[1:2, :n + 2])
+        assert np.abs(alone[0] - got[1, :n + 2]).max() < (2e-3 if precision == "fp32" else 0.05)
+
+
 def test_deep_ffn_takes_split_k_path():
     """d_ffn >= 2048 with few token rows: fc2 runs as parallel K-splits + one fixed-order reduction (weight-streaming kernel
     for a single chain, 64x64 tiles for a small batch).  Logits against the oracle, run-to-run bit equality, and the
