@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // MAXKB = number of 16-key blocks computed (T <= 16*MAXKB), even.  The dispatch ladder guarantees
 // T > 16*(MAXKB-6), so only the last 6 blocks can hold masked (>= T) keys.
-template <int MAXKB>
+template <int MAXKB, bool PADMASK>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                        SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         mx = fmaxf(mx, st[kb][r]);
       }
     }
-    if (key_tok) {
+    if (PADMASK) {
       // ragged batch (only reachable through the forward entry points; the Gibbs path never holds <pad>): keys that are
       // <pad> tokens get -inf like fair-esm's key_padding_mask.  key_tok = the token buffer, sequence `seq` at seq*T.
       const int32_t* kt = key_tok + (size_t)seq * T;
@@ -408,7 +408,8 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   dim3 grid((unsigned)(n_seq * H)), block(256);
 #define PG_ATT(KB)                                                                                             \
   else if (T <= KB * 16) {                                                                                     \
-    hipLaunchKernelGGL(attention_kernel<KB>, grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx); \
+    if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx); \
+    else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx); \
   }
   if (T <= 0) return fail(1, "attention: empty sequence");
   PG_ATT(2) PG_ATT(4) PG_ATT(8) PG_ATT(12) PG_ATT(18) PG_ATT(24) PG_ATT(30) PG_ATT(36)
