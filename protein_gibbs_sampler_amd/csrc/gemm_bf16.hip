@@ -491,7 +491,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 //     half-step; ping-pong on v_mfma_f32_32x32x16_bf16 (same MFMA busy cycles, more issue stalls);
 //   * 1 or 2 of the 4 DMA pieces issued inside the MFMA segment: -1 % / -2 %;
 //   * half of the first round's workgroups started half a tile late (to de-phase the chip-wide store bursts): 0 ... -2 %;
-//   * peeling the partial last round of tiles into a 128x128 launch: no gain (the dispatcher back-fills);
 //   * a "W-stationary" tile order (4-5 n-tiles at a time over a band of 32 m-panels, so their W panels stay in the XCD's
 //     L2 while X streams): 0 ... -2 % on all four shapes, although making EVERY DMA hit in L2 (ablation 17) is worth 14 %;
 //   * direct 16-B stores from the accumulators (16 rows x 64-B segments per instruction, possible with a permuted W-row
@@ -786,7 +785,28 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
     if (ok256) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
     if (ok128) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   }
-  if (ok256 && t256 >= 128) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  if (ok256 && t256 >= 128) {
+    // The 256^2 kernel runs (nearly) whole rounds of one tile per CU: time / ceil(tiles / 256) is the same 20 x 1.55 us per
+    // K = 1280 tile for all four shapes, so 1290 tiles cost 6 rounds, not 5.04.  When the last round would be less than
+    // half full, the m-panels beyond the full rounds are peeled off into a second, small GEMM, which the dispatch below
+    // gives to the 64^2 / 128^2 / split-K kernels (512 rows at config 2).  Measured: out-proj 0.283 -> 0.269 ms, fc2
+    // 0.800 -> 0.785, QKV and fc1 unchanged; whole iteration 92.7 -> 91.1 ms.  (An earlier attempt that peeled into the
+    // 128^2 kernel alone gained nothing.)
+    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    static const int peel_on = [] { const char* e = getenv("PGIBBS_GEMM_PEEL"); return e ? atoi(e) : 1; }();
+    const int tiles_n = N / 256, tiles_m = M / 256;
+    const long full = t256 / n_cu, frac = t256 - full * n_cu;
+    const int m_main = (int)(full * n_cu / tiles_n);
+    const int peel_rows = (tiles_m - m_main) * 256;
+    if (peel_on && frac > 0 && 2 * frac <= n_cu && full >= 2 && m_main > 0 && peel_rows <= 4096) {
+      int rc = launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi);
+      if (rc) return rc;
+      const size_t esz = (epi == EPI_BF16 || epi == EPI_BF16_GELU) ? 2 : 4;
+      return launch_gemm_bf16_variant(s, X + (size_t)m_main * 256 * ldx, W, bias, (char*)out + (size_t)m_main * 256 * ldo * esz,
+                                      peel_rows, N, K, ldx, ldw, ldo, epi, variant, ws, ws_bytes);
+    }
+    return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  }
   if (ok128 && (t128 >= 200 || !(M % 64 == 0))) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }
