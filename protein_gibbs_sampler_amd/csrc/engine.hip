@@ -249,7 +249,7 @@ int Engine::dense3(const bf16_t* xh, const bf16_t* xl, const DenseW& W, float* o
 // ------------------------------------------------------------------------------------------------
 // Scratch for the split-K form of a small fc2 GEMM (launch_gemm_bf16 decides whether to use it); nullptr for large M.
 float* Engine::splitk_ws(int rows, int n) {
-  if (rows > 2048) rows = 2048;        // large GEMMs only split the few m-panels peeled off their last, ragged round of tiles
+  if (rows > 2048) return nullptr;
   const size_t need = (size_t)5 * round_up(rows, kRowPad) * n * 4;
   if (splitk.bytes < need && splitk.ensure(need, stream)) return nullptr;
   return splitk.as<float>();
