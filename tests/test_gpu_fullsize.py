@@ -92,3 +92,45 @@ def test_config2_full_size_rows_are_independent(sampler):
     d = np.abs(few - full[-3:]).max()
     print("\nfull-size: 3 chains alone vs in the batch: max|diff| = %.3e (logit std %.2f)" % (d, full.std()))
     assert d < 0.05
+
+
+def test_config4_full_size_msa_gibbs_properties():
+    """BASELINE configuration 4 at full size (ESM-MSA-1b: 12 layers, d = 768; 64 MSAs x depth 32 x L = 256, 25 positions per
+    row): 51 200 position draws equal CPython's stream, every draw replays bit-exactly from the engine's logits, only the
+    selected positions change, and an MSA's logits do not depend on how many other MSAs share the batch."""
+    from protein_gibbs_sampler_amd import esm_msa_sampler
+    cfg = dict(weights.MSA1B_CONFIG)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = models.ESM_MSA1(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg)
+    s = esm_msa_sampler.ESM_MSA_sampler(m, device="cuda:0")
+    B, R, L, P = 64, 32, 256, 25
+    rng = np.random.default_rng(1234)
+    sym = np.asarray(list("ACDEFGHIKLMNPQRSTVWY"))
+    rows = sym[rng.integers(0, 20, (R, L))]
+    rows[rng.random((R, L)) < 0.1] = "-"
+    msa = ["".join(r) for r in rows]
+    s.draw_seed, s.record = 3, True
+    random.seed(0)
+    out = s.generate(B * R, msa, batch_size=B, num_iters=1, num_positions=P, top_k=0, temperature=1.0, burnin=float("inf"),
+                     show_progress_bar=False)
+    assert len(out) == B * R and all(len(x) == L for x in out)
+    run = s.last_run[0]
+    random.seed(0)
+    table = np.asarray([[[random.sample(range(1, L + 1), P) for _ in range(R)] for _ in range(B)]])
+    assert (run["table"] == table).all()
+    lg = run["sampled_logits"][0].reshape(-1, 33)
+    assert np.isfinite(lg).all()
+    want = odraw.draw_rows(lg, s.valid_aa_idx, 0, True, 1.0, np.repeat(np.arange(B * R), P), 0, np.tile(np.arange(P), B * R), 0, 3)
+    assert (want.reshape(B, R, P) == run["sampled_tokens"][0]).all()
+    tok = s.get_init_msa(msa, L, B).numpy().astype(np.int32)
+    start = tok.copy()
+    bi, ri = np.meshgrid(np.arange(B), np.arange(R), indexing="ij")
+    tok[bi[..., None], ri[..., None], table[0]] = want.reshape(B, R, P)
+    assert (tok == run["tokens"]).all()
+    touched = np.zeros_like(tok, dtype=bool)
+    touched[bi[..., None], ri[..., None], table[0]] = True
+    assert (tok[~touched] == start[~touched]).all() and np.isin(tok[touched], s.valid_aa_idx).all()
+    lm = m.model
+    full = lm.forward_logits(start[:16])
+    assert (lm.forward_logits(start[:8]) == full[:8]).all() and (lm.forward_logits(start[8:16]) == full[8:16]).all()
