@@ -372,7 +372,7 @@ int dbg_device(int device) {
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi) {
   if (precision != PG_PREC_BF16) return fail(PG_ERR_UNSUPPORTED, "only bf16");
-  if (!x || !w || !bias || !out || M < 1 || N % 128 || K % 64) return fail(PG_ERR_INVALID, "pg_dbg_gemm: bad argument");
+  if (!x || !w || !bias || !out || M < 1 || N % 64 || K % 64) return fail(PG_ERR_INVALID, "pg_dbg_gemm: bad argument");
   DeviceGuard g(-1);
   int rc = dbg_device(device);
   if (rc) return rc;

@@ -59,6 +59,32 @@ def test_gemm_bf16(M, N, K, epi):
     assert err < 2e-3 * max(1.0, np.abs(ref).max()), err      # fp32 accumulation-order noise only
 
 
+def test_gemm_dispatch_sweep():
+    """Seeded sweep over the dispatch branches (weight streaming, 64^2, 128^2, 256^2 ping-pong, peeled panels, split-K), all
+    epilogues: every branch must agree with numpy.  Shapes are drawn so that each branch is hit several times."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    for _ in range(10):                                   # small / medium M
+        cases.append((int(rng.integers(1, 1400)), int(rng.choice([128, 256, 320, 768, 1280])), int(rng.choice([64, 192, 768, 2048, 3072])),
+                      int(rng.choice([0, 1, 2, 3, 4]))))
+    for panels, N in ((103, 1280), (129, 1280), (65, 2304), (52, 2560), (131, 768)):       # >= 128 tiles of 256^2, ragged last rounds
+        cases.append((panels * 256 - int(rng.integers(0, 200)), N, int(rng.choice([128, 320])), int(rng.choice([0, 2, 3, 4]))))
+    for M, N, K, epi in cases:
+        x = rng.standard_normal((M, K), dtype=np.float32)
+        w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
+        b = rng.standard_normal(N, dtype=np.float32)
+        out = rng.standard_normal((M, N), dtype=np.float32)
+        res0 = out.copy()
+        _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_BF16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
+        ref = _bf16(x) @ _bf16(w).T + b
+        if epi in (1, 4):
+            ref = _gelu(ref.astype(np.float64)).astype(np.float32)
+        if epi == 2:
+            ref = ref + res0
+        tol = 3e-3 * max(1.0, float(np.abs(ref).max())) + (np.abs(ref) * 2.0 ** -8 if epi >= 3 else 0)
+        assert (np.abs(out - ref) <= tol).all(), (M, N, K, epi, float(np.abs(out - ref).max()))
+
+
 @pytest.mark.parametrize("M,d", [(5, 128), (1000, 1280), (33, 768), (7, 256)])
 def test_layernorm(M, d):
     rng = np.random.default_rng(d)
