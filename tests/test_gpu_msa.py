@@ -17,7 +17,9 @@ BF16_TOL = 0.15
 
 
 @pytest.mark.parametrize("B,R,C,H", [(2, 3, 20, 2), (1, 32, 257, 2), (2, 5, 70, 1), (1, 8, 130, 3), (1, 2, 300, 1),
-                                     (1, 128, 513, 1), (1, 37, 100, 2), (40, 9, 65, 12)])   # split-R and fused grids
+                                     (1, 128, 513, 1), (1, 37, 100, 2), (40, 9, 65, 12),
+                                     # width boundaries of the 4- / 9- / 8-wave instantiations, odd row counts in split-R
+                                     (1, 4, 64, 2), (1, 9, 288, 1), (1, 64, 289, 1), (3, 16, 384, 2), (2, 7, 450, 2), (1, 13, 576, 1)])
 def test_row_attention_kernel(B, R, C, H):
     rng = np.random.default_rng(C)
     d = H * 64
