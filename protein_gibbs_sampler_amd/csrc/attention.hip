@@ -4,16 +4,17 @@
 // `self.model.model(batch)["logits"]` (/root/reference/src/pgen/esm_sampler.py:223).
 //
 // CDNA4 mapping (head dim is 64 in ESM-1b and MSA-1b):
-//   * grid = B*H workgroups of 4 waves; K (row-major, XOR-swizzled 16-B chunks) and V^T live in LDS for
-//     the whole sequence (T <= 576: 72 KB + 74 KB) and are shared by all query blocks; longer sequences use
+//   * grid = B*H workgroups of 4 waves; K and V (both row-major, XOR-swizzled 16-B chunks) live in LDS for
+//     the whole sequence (T <= 576: 2 x 72 KB) and are shared by all query blocks; longer sequences use
 //     attention_long_kernel (288-key tiles, online softmax).
 //   * per wave, 16 queries at a time: S^T = K.Q^T with v_mfma_f32_16x16x32_bf16 ("swapped" product), so a
 //     lane holds, for ONE query (lane & 15), 4 consecutive keys of every 16-key block: the whole score
 //     row is lane-local except for a 4-lane (xor 16, 32) shuffle reduction -> exact (non-online) softmax
 //     in registers, no LDS round trip for P.
 //   * the K-slot order of the PV contraction is free, so it is chosen to be exactly the order the lane
-//     already holds P in (two 16-key blocks per 32-wide MFMA step); V^T rows in LDS then supply the
-//     matching 4+4 contiguous keys per lane with two conflict-free ds_read_b64.
+//     already holds P in (two 16-key blocks per 32-wide MFMA step); the matching V^T fragment (4 + 4 keys of one d per
+//     lane) comes straight out of the row-major V tile through gfx950's transposing LDS read ds_read_b64_tr_b16 -- no
+//     transposition pass when the tile is staged (that pass and its 4-byte LDS writes were 16 % of the kernel).
 //   * O^T = V^T.P^T, so a lane ends with 4 consecutive d for one query -> 8-byte row-major stores.
 #include "kernels.h"
 
@@ -24,14 +25,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // MAXKB = number of 16-key blocks computed (T <= 16*MAXKB), even.  The dispatch ladder guarantees
 // T > 16*(MAXKB-6), so only the last 6 blocks can hold masked (>= T) keys.
+typedef short v4s __attribute__((ext_vector_type(4)));
+
 template <int MAXKB, bool PADMASK>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                        SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx) {
-  constexpr int VT_LD = MAXKB * 16 + 8;  // bf16 elements per V^T row (592 B at MAXKB=18: conflict-free b64 reads)
-  __shared__ __attribute__((aligned(16))) char smem[MAXKB * 16 * 128 + 64 * VT_LD * 2];
+  __shared__ __attribute__((aligned(16))) char smem[2 * MAXKB * 16 * 128];
   char* Ks = smem;
-  bf16_t* Vt = (bf16_t*)(smem + MAXKB * 16 * 128);
+  char* Vs = smem + MAXKB * 16 * 128;          // V rows, same layout as K: row*128 + ((chunk ^ (row & 7)) << 4)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // sequence `seq` = token rows row0 + t*row_step (ESM: contiguous rows of chain b; MSA column attention: the R rows
@@ -45,29 +47,20 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   constexpr int nkc = MAXKB / 2;
   constexpr int tpad = MAXKB * 16;
 
-  // ---- stage K (swizzled rows) and V^T.  All global loads are issued before the first LDS write so a block pays
-  //      ~one memory round trip, not one per loop iteration (the loops have MAXKB/2 compile-time trips).
+  // ---- stage K and V (swizzled rows).  All global loads are issued before the first LDS write so a block pays
+  //      ~one memory round trip, not one per loop iteration.
   {
-    constexpr int NIT = (MAXKB * 16 * 8 + 255) / 256;       // K: one uint4 (8 d of one key) per item
-    constexpr int NVP = (MAXKB * 8 * 8 + 255) / 256;        // V: one item = 2 adjacent keys x 8 d
-    constexpr int hpad = tpad / 2;
-    uint4 kreg[NIT], va[NVP], vb[NVP];
+    constexpr int NIT = (MAXKB * 16 * 8 + 255) / 256;       // one uint4 (8 d of one key) per item
+    uint4 kreg[NIT], vreg[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = tid + it * 256;
       const int row = i >> 3, c = i & 7;
       kreg[it] = make_uint4(0, 0, 0, 0);
-      if (i < tpad * 8 && row < T) kreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + k_off + c * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < NVP; ++it) {
-      const int i = tid + it * 256;
-      const int kp = i % hpad, cv = i / hpad;   // lane <-> key pair: packed 4-byte transposed LDS writes, conflict-free
-      va[it] = make_uint4(0, 0, 0, 0);
-      vb[it] = make_uint4(0, 0, 0, 0);
-      if (i < hpad * 8) {
-        if (2 * kp < T) va[it] = *(const uint4*)(base + (size_t)(2 * kp) * ld_qkv + v_off + cv * 8);
-        if (2 * kp + 1 < T) vb[it] = *(const uint4*)(base + (size_t)(2 * kp + 1) * ld_qkv + v_off + cv * 8);
+      vreg[it] = make_uint4(0, 0, 0, 0);
+      if (i < tpad * 8 && row < T) {
+        kreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + k_off + c * 8);
+        vreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + v_off + c * 8);
       }
     }
 #pragma unroll
@@ -76,20 +69,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       if (i < tpad * 8) {
         const int row = i >> 3, c = i & 7;
         *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < NVP; ++it) {
-      const int i = tid + it * 256;
-      if (i < hpad * 8) {
-        const int kp = i % hpad, cv = i / hpad;
-        const uint32_t a[4] = {va[it].x, va[it].y, va[it].z, va[it].w}, b[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
-        uint32_t* vt32 = (uint32_t*)Vt;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu, hi = (b[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-          vt32[((cv * 8 + e) * VT_LD) / 2 + kp] = lo | (hi << 16);
-        }
+        *(uint4*)(Vs + row * 128 + ((c ^ (row & 7)) << 4)) = vreg[it];
       }
     }
   }
@@ -194,9 +174,17 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       auto load_v = [&](int c, VF (&dst)[4]) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
-          dst[db].h[0] = *(const uint2*)(vrow);
-          dst[db].h[1] = *(const uint2*)(vrow + 16);
+          // transposed LDS read (semantics probed on the device): the 16 lanes of a group point at 4 key rows x four 8-byte
+          // pieces of 16 d (lane s -> row s>>2, piece s&3) and lane fr receives V[key0 .. key0+3][d = db*16 + fr]
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int krow = (2 * c + hh) * 16 + fq * 4 + (fr >> 2);
+            const int dcol = db * 16 + (fr & 3) * 4;                                     // bf16 index inside the key row
+            const char* a = Vs + krow * 128 + (((dcol >> 3) ^ (krow & 7)) << 4) + ((dcol >> 2) & 1) * 8;
+            const v4s t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
+                (__attribute__((address_space(3))) char*)a));
+            dst[db].h[hh] = __builtin_bit_cast(uint2, t);
+          }
         }
       };
       load_v(0, vbuf[0]);
@@ -243,10 +231,10 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
                                                                int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                                SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok,
                                                                int pad_idx) {
-  constexpr int MAXKB = 18, tpad = MAXKB * 16, nkc = MAXKB / 2, VT_LD = tpad + 8;
-  __shared__ __attribute__((aligned(16))) char smem[tpad * 128 + 64 * VT_LD * 2];
+  constexpr int MAXKB = 18, tpad = MAXKB * 16, nkc = MAXKB / 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128];
   char* Ks = smem;
-  bf16_t* Vt = (bf16_t*)(smem + tpad * 128);
+  char* Vs = smem + tpad * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qc = blockIdx.x % n_qchunk, sh = blockIdx.x / n_qchunk;
   const int seq = sh / H, h = sh % H;
@@ -271,39 +259,25 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
 
   for (int k0 = 0; k0 < T; k0 += tpad) {
     __syncthreads();
-    {   // stage this key tile: K rows swizzled, V^T packed two keys per 32-bit word (as in attention_kernel)
-      constexpr int NIT = (tpad * 8 + 255) / 256, NVP = (tpad / 2 * 8 + 255) / 256, hpad = tpad / 2;
-      uint4 kreg[NIT], va[NVP], vb[NVP];
+    {   // stage this key tile: K and V rows, swizzled (as in attention_kernel)
+      constexpr int NIT = (tpad * 8 + 255) / 256;
+      uint4 kreg[NIT], vreg[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int i = tid + it * 256, row = i >> 3, c = i & 7;
         kreg[it] = make_uint4(0, 0, 0, 0);
-        if (i < tpad * 8 && k0 + row < T) kreg[it] = *(const uint4*)(base + (size_t)(k0 + row) * ld_qkv + k_off + c * 8);
-      }
-#pragma unroll
-      for (int it = 0; it < NVP; ++it) {
-        const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
-        va[it] = make_uint4(0, 0, 0, 0);
-        vb[it] = make_uint4(0, 0, 0, 0);
-        if (i < hpad * 8) {
-          if (k0 + 2 * kp < T) va[it] = *(const uint4*)(base + (size_t)(k0 + 2 * kp) * ld_qkv + v_off + cv * 8);
-          if (k0 + 2 * kp + 1 < T) vb[it] = *(const uint4*)(base + (size_t)(k0 + 2 * kp + 1) * ld_qkv + v_off + cv * 8);
+        vreg[it] = make_uint4(0, 0, 0, 0);
+        if (i < tpad * 8 && k0 + row < T) {
+          kreg[it] = *(const uint4*)(base + (size_t)(k0 + row) * ld_qkv + k_off + c * 8);
+          vreg[it] = *(const uint4*)(base + (size_t)(k0 + row) * ld_qkv + v_off + c * 8);
         }
       }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int i = tid + it * 256, row = i >> 3, c = i & 7;
-        if (i < tpad * 8) *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
-      }
-#pragma unroll
-      for (int it = 0; it < NVP; ++it) {
-        const int i = tid + it * 256, kp = i % hpad, cv = i / hpad;
-        if (i < hpad * 8) {
-          const uint32_t a[4] = {va[it].x, va[it].y, va[it].z, va[it].w}, b[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
-          uint32_t* vt32 = (uint32_t*)Vt;
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            vt32[((cv * 8 + e) * VT_LD) / 2 + kp] = ((a[e >> 1] >> ((e & 1) * 16)) & 0xffffu) | (((b[e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
+        if (i < tpad * 8) {
+          *(uint4*)(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[it];
+          *(uint4*)(Vs + row * 128 + ((c ^ (row & 7)) << 4)) = vreg[it];
         }
       }
     }
@@ -374,9 +348,14 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         union { bf16x8 v; uint2 h2[2]; } vf;
-        const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
-        vf.h2[0] = *(const uint2*)(vrow);
-        vf.h2[1] = *(const uint2*)(vrow + 16);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {                       // transposed LDS read, see attention_kernel
+          const int krow = (2 * c + hh) * 16 + fq * 4 + (fr >> 2);
+          const int dcol = db * 16 + (fr & 3) * 4;
+          const char* a = Vs + krow * 128 + (((dcol >> 3) ^ (krow & 7)) << 4) + ((dcol >> 2) & 1) * 8;
+          vf.h2[hh] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
+                                                    (__attribute__((address_space(3))) char*)a)));
+        }
         o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[db], 0, 0, 0);
       }
     }
