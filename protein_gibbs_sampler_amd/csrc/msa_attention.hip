@@ -7,7 +7,8 @@
 // One workgroup = (msa b, head h, NW*16 queries); wave w owns 16 of them.  Pass 1 streams K_r (C x 64) through LDS for
 // r = 0..R-1 and accumulates the S^T blocks of the wave's 16 queries in registers with v_mfma_f32_16x16x32_bf16
 // (the same lane-local layout as attention.hip: a lane holds one query's scores for 4 keys of every 16-key block),
-// then one exact softmax; pass 2 streams V_r^T through LDS and emits ctx for every row with the same P fragments.
+// then one exact softmax; pass 2 streams V_r through LDS the same way (V^T fragments via ds_read_b64_tr_b16) and emits
+// ctx for every row with the same P fragments.
 // Every workgroup of a (msa, head) re-streams all R tiles, so the workgroup is made as wide as the registers allow:
 // NW = 9 waves cover C = 257 columns (bos + 256) in 2 workgroups instead of 5 (the 5th held a single query).
 // The tiles alternate between two LDS buffers (one barrier per row) and are fetched into registers two rows ahead
@@ -30,14 +31,11 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
   // mode 3: (one workgroup per (msa, head, query block)) S = sum of the n_rc partial maps in fixed order, softmax,
   //         P as bf16 MFMA fragments -> pfrag (16 B per lane and fragment, stored behind the partial maps);
   // mode 2: pass 2 over the row chunk rc only with the P fragments of mode 3.
-  constexpr int VT_LD = MAXKB * 16 + 8;
-  constexpr int tpad = MAXKB * 16, hpad = tpad / 2;
+  constexpr int tpad = MAXKB * 16;
   constexpr int NT = NW * 64;                      // threads
-  constexpr int NIT = (tpad * 8 + NT - 1) / NT;    // K items per thread: one uint4 = 8 d of one key
-  constexpr int NVP = (hpad * 8 + NT - 1) / NT;    // V items per thread: two adjacent keys x 8 d
+  constexpr int NIT = (tpad * 8 + NT - 1) / NT;    // tile items per thread: one uint4 = 8 d of one key
   constexpr int AHEAD = (MAXKB <= 18 && NIT <= 9) ? 2 : 1;   // rows fetched ahead into registers (register budget)
-  constexpr int BUF = 64 * VT_LD * 2;              // one tile buffer: V^T (64 x VT_LD bf16) >= K (tpad x 128 B)
-  static_assert(BUF >= MAXKB * 16 * 128, "tile buffer");
+  constexpr int BUF = tpad * 128;                  // one tile buffer: tpad key rows of 128 B (K_r in pass 1, V_r in pass 2)
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   // mode 3 is launched with one wave per workgroup (the reduction has no LDS phase; this spreads it over the chip):
@@ -81,13 +79,13 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
   // row r + 2 right away, so a tile has two rows of MFMAs to arrive.
   struct KRegs { uint4 k[NIT]; };                    // one row's K tile share
   KRegs kA, kB;
-  auto load_k = [&](KRegs& g, int r) {
+  auto load_k = [&](KRegs& g, int r, int off) {
     const bf16_t* rb = base + (size_t)r * C * ld_qkv;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = tid + it * NT, row = i >> 3, c = i & 7;
       g.k[it] = make_uint4(0, 0, 0, 0);
-      if (i < tpad * 8 && row < C) g.k[it] = *(const uint4*)(rb + (size_t)row * ld_qkv + k_off + c * 8);
+      if (i < tpad * 8 && row < C) g.k[it] = *(const uint4*)(rb + (size_t)row * ld_qkv + off + c * 8);
     }
   };
   auto score_row = [&](KRegs& g, int r) {
@@ -100,7 +98,7 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
     const bf16_t* qp = base + ((size_t)r * C + qrow) * ld_qkv + fq * 8;     // in flight across the barrier
     const bf16x8 qf0 = *(const bf16x8*)qp, qf1 = *(const bf16x8*)(qp + 32);
     __syncthreads();                                  // tile r visible; everybody is done with tile r - 1 (other buffer)
-    if (r + AHEAD < r_hi) load_k(g, r + AHEAD);
+    if (r + AHEAD < r_hi) load_k(g, r + AHEAD, k_off);
     if (active) {
       // the two k-halves of a key block accumulate into the same registers: keep them MAXKB MFMAs apart
 #pragma unroll
@@ -115,9 +113,9 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
     }
   };
   if (mode < 2) {
-    if (r_lo < r_hi) load_k(kA, r_lo);
+    if (r_lo < r_hi) load_k(kA, r_lo, k_off);
     if (AHEAD == 2) {
-      if (r_lo + 1 < r_hi) load_k(kB, r_lo + 1);
+      if (r_lo + 1 < r_hi) load_k(kB, r_lo + 1, k_off);
       for (int r = r_lo; r < r_hi; r += 2) {
         score_row(kA, r);
         if (r + 1 < r_hi) score_row(kB, r + 1);
@@ -198,37 +196,19 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
     }
   }
 
-  // ---- pass 2: ctx[r] = P . V_r for every row (V_r^T tiles: same two-buffer, two-rows-ahead scheme) ----------------
-  struct VRegs { uint4 a[NVP], b[NVP]; };
-  VRegs vA, vB;
-  auto load_v = [&](VRegs& v, int r) {
-    const bf16_t* rb = base + (size_t)r * C * ld_qkv;
+  // ---- pass 2: ctx[r] = P . V_r for every row.  V_r tiles are staged exactly like the K_r tiles (row-major, swizzled,
+  // two buffers, fetched AHEAD rows ahead); the V^T fragments of the PV MFMAs come out of them through the transposing
+  // LDS read ds_read_b64_tr_b16 (see attention.hip) -- the former transposition pass was most of this kernel's VALU work.
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  auto apply_row = [&](KRegs& g, int r, int slot) {
+    char* Vs = smem + slot * BUF;
 #pragma unroll
-    for (int it = 0; it < NVP; ++it) {
-      const int i = tid + it * NT, kp = i % hpad, cv = i / hpad;
-      v.a[it] = make_uint4(0, 0, 0, 0);
-      v.b[it] = make_uint4(0, 0, 0, 0);
-      if (i < hpad * 8) {
-        if (2 * kp < C) v.a[it] = *(const uint4*)(rb + (size_t)(2 * kp) * ld_qkv + v_off + cv * 8);
-        if (2 * kp + 1 < C) v.b[it] = *(const uint4*)(rb + (size_t)(2 * kp + 1) * ld_qkv + v_off + cv * 8);
-      }
-    }
-  };
-  auto apply_row = [&](VRegs& v, int r, int slot) {
-    bf16_t* Vt = (bf16_t*)(smem + slot * BUF);
-#pragma unroll
-    for (int it = 0; it < NVP; ++it) {
-      const int i = tid + it * NT, kp = i % hpad, cv = i / hpad;
-      if (i < hpad * 8) {
-        const uint32_t a[4] = {v.a[it].x, v.a[it].y, v.a[it].z, v.a[it].w}, bb[4] = {v.b[it].x, v.b[it].y, v.b[it].z, v.b[it].w};
-        uint32_t* vt32 = (uint32_t*)Vt;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          vt32[((cv * 8 + e) * VT_LD) / 2 + kp] = ((a[e >> 1] >> ((e & 1) * 16)) & 0xffffu) | (((bb[e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
-      }
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * NT, row = i >> 3, c = i & 7;
+      if (i < tpad * 8) *(uint4*)(Vs + row * 128 + ((c ^ (row & 7)) << 4)) = g.k[it];
     }
     __syncthreads();
-    if (r + AHEAD < r_hi) load_v(v, r + AHEAD);
+    if (r + AHEAD < r_hi) load_k(g, r + AHEAD, v_off);
     if (active) {
       f32x4 o[4];
 #pragma unroll
@@ -238,9 +218,14 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           union { bf16x8 v; uint2 h2[2]; } vf;
-          const bf16_t* vrow = Vt + (db * 16 + fr) * VT_LD + c * 32 + fq * 4;
-          vf.h2[0] = *(const uint2*)(vrow);
-          vf.h2[1] = *(const uint2*)(vrow + 16);
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int krow = (2 * c + hh) * 16 + fq * 4 + (fr >> 2);
+            const int dcol = db * 16 + (fr & 3) * 4;
+            const char* a = Vs + krow * 128 + (((dcol >> 3) ^ (krow & 7)) << 4) + ((dcol >> 2) & 1) * 8;
+            vf.h2[hh] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
+                                                      (__attribute__((address_space(3))) char*)a)));
+          }
           o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[c].v, o[db], 0, 0, 0);
         }
       }
@@ -258,15 +243,15 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
     }
   };
   __syncthreads();                                    // pass 1's last tile (either buffer) fully consumed
-  if (r_lo < r_hi) load_v(vA, r_lo);
+  if (r_lo < r_hi) load_k(kA, r_lo, v_off);
   if (AHEAD == 2) {
-    if (r_lo + 1 < r_hi) load_v(vB, r_lo + 1);
+    if (r_lo + 1 < r_hi) load_k(kB, r_lo + 1, v_off);
     for (int r = r_lo; r < r_hi; r += 2) {
-      apply_row(vA, r, 0);
-      if (r + 1 < r_hi) apply_row(vB, r + 1, 1);
+      apply_row(kA, r, 0);
+      if (r + 1 < r_hi) apply_row(kB, r + 1, 1);
     }
   } else {
-    for (int r = r_lo; r < r_hi; ++r) apply_row(vA, r, (r - r_lo) & 1);
+    for (int r = r_lo; r < r_hi; ++r) apply_row(kA, r, (r - r_lo) & 1);
   }
 }
 
