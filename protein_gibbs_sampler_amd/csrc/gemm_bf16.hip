@@ -753,6 +753,8 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
         rc = mt <= 1 ? launch_skinny_mt<1>(s, X, W, bias, ws, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride)
            : mt <= 2 ? launch_skinny_mt<2>(s, X, W, bias, ws, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride)
                      : launch_skinny_mt<4>(s, X, W, bias, ws, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride);
+      } else if (Mr % 128 == 0 && N % 128 == 0 && (long)(Mr / 128) * (N / 128) * splits >= 256) {
+        rc = launch_cfg<128, 128, 64, 64>(s, X, W, bias, ws, Mr, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride);   // enough 128^2 tiles
       } else {
         rc = launch_cfg<64, 64, 32, 32>(s, X, W, bias, ws, Mr, N, Ks, ldx, ldw, N, EPI_F32_PARTIAL, splits, stride);
       }
