@@ -8,15 +8,21 @@
 // Design (CDNA4, 64-wide waves):
 //   * both operands are K-contiguous ([rows][K], PyTorch Linear layout), so W rows feed the MFMA
 //     A operand and activation rows the B operand: D[n][m].  A lane then holds 4 consecutive n
-//     for one token m -> 8-byte bf16 / 16-byte fp32 row-major stores, no transpose.
-//   * 256x256x64 block tile, 8 waves (2 over m x 4 over n), wave tile 128(m) x 64(n),
-//     v_mfma_f32_16x16x32_bf16; 128x128 variant (4 waves) for narrow shapes.
-//   * HBM/L2 -> LDS by direct `global_load_lds` (16 B/lane, no VGPR round trip), double-buffered;
-//     LDS rows are 128 B (64 k) and 16-B chunks are XOR-swizzled with (row & 7) by permuting the
-//     per-lane SOURCE address (the LDS image of a glds is lane-linear), so every ds_read_b128
+//     for one token m.
+//   * four kernels, picked by how many tiles they put on the 256 CUs (launch_gemm_bf16_variant):
+//       - 256x256x64 ping-pong kernel (gemm_bf16_pp_kernel): 8 waves as two staggered groups, LDS-DMA ring of four
+//         half-K buffers, LDS-staged coalesced epilogues with non-temporal stores; m-panels of a ragged last round of
+//         tiles are peeled into a second, small launch;
+//       - 128x128 and 64x64 lockstep double-buffered tiles (gemm_bf16_kernel) for 64 .. ~4000 token rows;
+//       - weight-streaming kernel (gemm_bf16_skinny_kernel) up to 48 rows;
+//       - deep-K residual GEMMs with few tiles run as parallel K-splits + a fixed-order reduction.
+//     Every path accumulates a row's products in the same k order, so large batches are bit-identical however the
+//     rows are split over launches or GPUs (only the split-K path of small batches differs, by rounding).
+//   * HBM/L2 -> LDS by direct `global_load_lds` (16 B/lane, no VGPR round trip); 16-B LDS chunks are XOR-swizzled by
+//     permuting the per-lane SOURCE address (the LDS image of a glds is lane-linear), so every ds_read_b128
 //     lane group touches 16 distinct 16-B slots (conflict-free).
 //   * 1-D grid remapped so each XCD (private L2) owns a contiguous range of tiles.
-//   * epilogues fused: +bias, erf-GELU, bf16 pack, fp32 residual read-modify-write.
+//   * epilogues fused: +bias, GELU, bf16 pack, fp32 residual read-modify-write.
 #include <stdlib.h>
 
 #include "kernels.h"

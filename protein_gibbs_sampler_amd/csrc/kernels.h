@@ -13,12 +13,14 @@ struct SeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_GELU = 4,
        EPI_F32_PARTIAL = 5 /* internal: split-K partial sums, no bias */ };
 
-// out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M, N multiples of 128, K of 64 (buffers are row-padded).
+// out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M a multiple of 16 up to 256 rows, of 128 beyond; N a multiple of 64; K of 64
+// (activation buffers are padded to 256 rows: kernels may touch the padding rows of the last tile).
 // ws (optional, fp32 scratch): lets a residual GEMM with few tiles and a deep K (fc2 of a small batch) run as parallel
 // K-splits into ws followed by one fixed-order reduction into out -- bit-reproducible, no atomics.
 int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, float* ws = nullptr, size_t ws_bytes = 0);
-// variant: 1 = lockstep double-buffered kernel, 2 = ping-pong kernel (default), used by the micro-benchmark entry
+// variant: 1 = lockstep tiles only, 2 = default dispatch, 6 / 7 = force 64^2 / 128^2 tiles, 21.. = ablations of the
+// ping-pong kernel (micro-benchmark entry)
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws = nullptr, size_t ws_bytes = 0);
 
