@@ -16,8 +16,8 @@
 //       - 128x128 and 64x64 lockstep double-buffered tiles (gemm_bf16_kernel) for 64 .. ~4000 token rows;
 //       - weight-streaming kernel (gemm_bf16_skinny_kernel) up to 48 rows;
 //       - deep-K residual GEMMs with few tiles run as parallel K-splits + a fixed-order reduction.
-//     Every path accumulates a row's products in the same k order, so large batches are bit-identical however the
-//     rows are split over launches or GPUs (only the split-K path of small batches differs, by rounding).
+//     The tile kernels accumulate a row's products in the same k order, so large batches are bit-identical however the
+//     rows are split over launches or GPUs (the weight-streaming and split-K paths of small batches differ, by rounding).
 //   * HBM/L2 -> LDS by direct `global_load_lds` (16 B/lane, no VGPR round trip); 16-B LDS chunks are XOR-swizzled by
 //     permuting the per-lane SOURCE address (the LDS image of a glds is lane-linear), so every ds_read_b128
 //     lane group touches 16 distinct 16-B slots (conflict-free).
