@@ -135,3 +135,45 @@ def test_clean_fasta(tmp_path):
     assert dst.read_text() == ">s1\nMKVAA\n>s2\nACDEF\n>s3\nGHIK\n"
     clean_fasta.main(["-i", str(src), "-o", str(dst), "--clean_strategy", "delete", "--full_name"])
     assert dst.read_text() == ">s1 desc\nMK-VAA\n>s2\n-DEF\n>s3\n--GHIK--\n"
+
+
+def test_tool_wrappers_with_mocked_subprocess(monkeypatch, tmp_path):
+    """run_phmmer / generate_alignment / add_to_msa: the command lines the reference uses (utils.py:251,294-297,196) and the
+    parsing of what comes back, with subprocess.run replaced by canned phmmer / mafft / muscle outputs."""
+    calls = []
+
+    class Res:
+        def __init__(self, out, rc=0, as_bytes=False):
+            self.stdout = out.encode() if as_bytes else out
+            self.stderr = b"" if as_bytes else ""
+            self.returncode = rc
+
+    def fake_run(argv, **kw):
+        calls.append(list(argv))
+        if argv[0] == "phmmer":
+            assert open(argv[-2]).read() == ">QUERY\nMKVA\n"            # the query FASTA the wrapper wrote
+            return Res(PHMMER_REPORT)
+        if argv[0] == "mafft":
+            seqs = [l.strip() for l in open(argv[-1]) if not l.startswith(">")]
+            names = [l.strip()[1:] for l in open(argv[-1]) if l.startswith(">")]
+            width = max(map(len, seqs))
+            return Res("".join(">%s\n%s\n" % (n, s + "-" * (width - len(s))) for n, s in zip(names, seqs)), as_bytes=True)
+        if argv[0] == "muscle":
+            old = [l.strip() for l in open(argv[argv.index("-in1") + 1]) if not l.startswith(">")]
+            return Res("".join(">%d\n%s-\n" % (i, s) for i, s in enumerate(old)) + ">new_seq\nMKVAA\n")
+        raise AssertionError(argv)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    assert msa_tools.run_phmmer("MKVA", tmp_path / "db.fasta", max_mode=True) == ["2", "0", "3"]
+    assert calls[-1][:7] == ["phmmer", "--noali", "--notextw", "--cpu", "2", "-E", "10"] and "--max" in calls[-1]
+    names, aligned = msa_tools.generate_alignment({"1": ["MKV", "MKVAA", "M"]}, ep=0.25, op=2.0)
+    assert names == ["1_0", "1_1", "1_2"] and aligned == ["MKV--", "MKVAA", "M----"]
+    assert calls[-1][:10] == ["mafft", "--thread", "8", "--maxiterate", "1000", "--globalpair", "--ep", "0.25", "--op", "2.0"]
+    assert msa_tools.add_to_msa(["MKVA", "MRVA"], "MKVAA") == ["MKVAA", "MKVA-", "MRVA-"]   # new sequence moved to the top
+    assert calls[-1][:2] == ["muscle", "-profile"]
+    monkeypatch.setattr(subprocess, "run", lambda argv, **kw: Res("", rc=1, as_bytes=True))
+    with pytest.raises(Exception, match="mafft failed"):
+        msa_tools.generate_alignment({"1": ["MKV"]})
+    monkeypatch.setattr(subprocess, "run", lambda argv, **kw: Res("boom", rc=2))
+    with pytest.raises(SystemExit):
+        msa_tools.run_phmmer("MKVA", tmp_path / "db.fasta")

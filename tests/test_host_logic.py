@@ -177,3 +177,29 @@ def test_esm_position_tables_bit_exact(esm, name):
 def test_duplicate_indexes_are_shadowed():
     t, _ = _gibbs.build_target_table(1, (2,), [3, 5, 3, 7], 0, False, -1)
     assert t[0, 0].tolist() == [3 | _gibbs.SHADOW_BIT, 5, 3, 7]
+
+
+def test_fair_esm_checkpoint_layout_round_trip(tmp_path):
+    """A `.pt` in fair-esm's layout ({"model": {"encoder.sentence_encoder.<key>": tensor, ...}, "args": ...}, tied decoder
+    stored as `lm_head.weight`, extra buffers such as `contact_head.*`) loads into the engine's key set."""
+    import torch
+    from protein_gibbs_sampler_amd import weights
+    cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=64, n_layers=2, d_ffn=128, max_positions=20)
+    sd = weights.synthetic_state_dict(cfg, seed=3)
+    blob = {"model": {}, "args": {"arch": "roberta_large"}}
+    for k, v in sd.items():
+        if k == "embed_tokens.weight":
+            blob["model"]["encoder.lm_head.weight"] = torch.from_numpy(v).clone()     # only the tied copy is present
+            continue
+        blob["model"]["encoder.sentence_encoder." + k if not k.startswith("lm_head") else "encoder." + k] = torch.from_numpy(v).double()
+    blob["model"]["encoder.sentence_encoder.contact_head.regression.weight"] = torch.zeros(1, 40)
+    path = tmp_path / "esm_tiny.pt"
+    torch.save(blob, path)
+    got = weights.load_fair_esm_checkpoint(str(path), cfg)
+    assert set(got) == set(sd)
+    for k in sd:
+        assert got[k].dtype == np.float32 and got[k].shape == sd[k].shape and (got[k] == sd[k]).all(), k
+    del blob["model"]["encoder.sentence_encoder.layers.1.fc2.bias"]
+    torch.save(blob, path)
+    with pytest.raises(KeyError, match="missing 1 tensors"):
+        weights.load_fair_esm_checkpoint(str(path), cfg)
