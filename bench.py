@@ -1,40 +1,84 @@
 #!/usr/bin/env python3
-"""Headline benchmark: sampled positions / second of the ESM-1b Gibbs hot path (BASELINE.json configs[1]).
+"""Headline benchmark: sampled positions / second of the ESM-1b Gibbs hot path (BASELINE.json configs[1] at N = 1,
+configs[2] -- the same 256 chains sharded over N GPUs -- at N > 1).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+      N = 1: runs in this process.  N > 1 without a launcher: re-executes itself under
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`; the driver's own
+      torchrun command line works too (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment).
 
-A "step" is one Gibbs iteration over the batch resident on one GPU: draw P = 25 positions for each of
-B = 256 chains of L = 256 residues (CPython-exact random.sample stream, native), scatter <mask>, run
-the 33-layer ESM-1b forward (T = 258 tokens per chain), evaluate the LM head at the sampled rows, draw
-tokens (top_k = 0, temperature = 1, burnin = inf) and write them back -- all inside one C-ABI call
-(pg_esm_gibbs_run_device) with the token buffer resident in HBM.  Weights are seeded synthetic weights
-of the ESM-1b architecture (no checkpoints offline); throughput does not depend on their values.
+A "step" is one Gibbs iteration over the chains resident on one GPU: draw P = 25 positions for each chain of L = 256
+residues (CPython-exact random.sample stream, native), scatter <mask>, run the 33-layer ESM-1b forward (T = 258 tokens
+per chain), evaluate the LM head at the sampled rows, draw tokens (top_k = 0, temperature = 1, burnin = inf) and write
+them back -- all inside one C-ABI call (pg_esm_gibbs_run_device) with the token buffer resident in HBM.  Weights are
+seeded synthetic weights of the ESM-1b architecture (no checkpoints offline); throughput does not depend on their values.
 
-Multi-GPU: chains are independent, so each rank owns a contiguous block of chains (weak scaling:
-256 chains per GPU) and the only collective is one RCCL all-gather of the final token buffers.
+Multi-GPU (BASELINE config 3): the SAME 256 chains split contiguously, GPU g owns chains
+[g*256/N, (g+1)*256/N) -- "scaling": "strong".  Chains never interact, so there is no data-path collective; the only
+collective is one RCCL all-gather of the final token buffers.  Every rank derives its slice of the position table from the
+one CPython-exact stream and token draws are keyed by global chain id, so the gathered result is bit-identical to the
+N = 1 result: rank 0 re-runs the whole job on its own GPU after the timed region and asserts that (`verified_vs_single_gpu`).
+`--weak` keeps 256 chains per GPU instead.
 
 Output: ONE JSON line (rank 0) with the driver's contract plus
-  roofline     -- the GEMM kernel family (96.5 % of the FLOPs): algorithmic FLOPs / HIP-event time
-  cpu_baseline -- the fp32 CPU oracle (numpy/OpenBLAS port of the same path) on a bounded sample
+  roofline     -- the GEMM kernel family (96.5 % of the FLOPs): executed FLOPs / HIP-event time on the engine's stream
+  strict_mode  -- (N = 1) the same workload in the parity mode (PG_PREC_FP32: split-bf16 x3 GEMMs, fp32 attention): its
+                  positions/s and its measured max |logit error| against the fp32 oracle -- the mode north_star's 1e-3
+                  tolerance refers to; `bf16_max_abs_logit_err` is the same measurement for the benchmarked mode
+  cpu_baseline -- the fp32 CPU oracle (numpy/OpenBLAS port of the same path; the checker, never the product) on a bounded
+                  sample, plus config 1 in full and the reference-style per-position sampling-loop cost
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-import warnings
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from protein_gibbs_sampler_amd import _lib, models, pyrandom, sharding, weights  # noqa: E402
-
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+TOTAL_CHAINS = 256                 # BASELINE.json configs[1] / configs[2]
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--weak", action="store_true", help="weak scaling: 256 chains PER GPU instead of 256 in total")
+    ap.add_argument("--chains", type=int, default=TOTAL_CHAINS, help="chains in total (per GPU with --weak)")
+    ap.add_argument("--length", type=int, default=256)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="mode of the timed run: bf16 = throughput mode (the headline), fp32 = strict parity mode")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the JSON then says so)")
+    ap.add_argument("--greedy-after-burnin", action="store_true",
+                    help="SURVEY 8d variant: top_k=1, burnin=25 (argmax after 25 sampled iterations) instead of all-sampling")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo for dry runs")
+    ap.add_argument("--oversubscribe", action="store_true", help="testing: ranks share GPUs (LOCAL_RANK mod device count); implies gloo")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work at all: launcher, sharding, position tables and the gather only (CPU container check)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the N > 1 bit-equality check against a single-GPU run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict-mode leg (N = 1)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: one rank per GPU under torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def gemm_flops_per_iter(cfg, n_tokens, n_sampled):
@@ -49,170 +93,265 @@ def total_flops_per_iter(cfg, n_tokens, T, n_sampled):
 
 
 def measured_gemm_traffic():
-    """Fabric (L2 -> Infinity Cache/HBM) bytes per GEMM launch from the committed PMC passes
-    (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, calibrated on the LayerNorm
-    kernel whose traffic is known exactly).  None when the profile file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
-    if not os.path.exists(path):
-        return None
-    k = json.load(open(path))["kernels"]
+    """Fabric (L2 <-> Infinity Cache/HBM) bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.sh:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, calibrated on the LayerNorm kernel whose traffic is known
+    exactly).  The newest profiles/rNN_hbm_traffic_pmc.json wins; None when there is none."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
+    if not paths:
+        return None, None
+    k = json.load(open(paths[-1]))["kernels"]
     gem = [(v["launches"], v["read_MB_per_launch"] + v["write_MB_per_launch"]) for n, v in k.items()
-           if "gemm_bf16_pp_kernel<0" in n or "gemm_bf16_pp_kernel<1" in n or "gemm_bf16_pp_kernel<2" in n]
+           if any(t in n for t in ("gemm_bf16_pp_kernel", "gemm_bf16_w4_kernel"))]      # the big-tile kernels (not the peeled panels)
     if not gem:
-        return None
-    return 1e6 * sum(n * mb for n, mb in gem) / sum(n for n, _ in gem)
+        return None, os.path.basename(paths[-1])
+    return 1e6 * sum(n * mb for n, mb in gem) / sum(n for n, _ in gem), os.path.basename(paths[-1])
 
 
-def cpu_baseline(cfg, sd, B, L, P, valid_idx, target_seconds=15.0):
-    """Times the CPU oracle (checker, never the product) on a bounded sample of the same workload:
-    b chains x one full Gibbs iteration (mask, fp32 forward, draw).  Scales linearly in chains."""
+def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, target_seconds=12.0):
+    """The CPU oracle (checker, never the product) timed on a bounded sample of the same workload -- b chains x one full
+    Gibbs iteration (mask, fp32 forward, draw), linear in chains -- and used as the checker of the engines' logits on those
+    very chains.  Plus BASELINE.md section 3's two other asks: config 1 in full and the reference-style per-position loop."""
+    import numpy as np
     from threadpoolctl import threadpool_info
     from oracle import draw as odraw
     from oracle.esm_forward import EsmConfig, esm1b_trunk, lm_head
     ocfg = EsmConfig(vocab=cfg["vocab"], d_model=cfg["d_model"], n_layers=cfg["n_layers"], n_heads=cfg["n_heads"],
                      d_ffn=cfg["d_ffn"], max_pos=cfg["max_positions"])
     rng = np.random.default_rng(1234)
+    keep = {}
 
-    def one(b):
-        tok = np.concatenate([np.zeros((b, 1), np.int64), rng.integers(4, 24, (b, L)), np.full((b, 1), 2)], axis=1)
-        idx = np.stack([rng.choice(np.arange(1, L + 1), P, replace=False) for _ in range(b)])
+    def one(b, T_len=L, n_pos=P, top_k=0, sample=True):
+        tok = np.concatenate([np.zeros((b, 1), np.int64), rng.integers(4, 24, (b, T_len)), np.full((b, 1), 2)], axis=1)
+        idx = np.stack([rng.choice(np.arange(1, T_len + 1), n_pos, replace=False) for _ in range(b)])
         t0 = time.perf_counter()
         for i in range(b):
             tok[i, idx[i]] = cfg["mask_idx"]
+        keep["masked"] = tok.copy()
         x = esm1b_trunk(sd, ocfg, tok)
-        rows = np.stack([x[i, idx[i]] for i in range(b)]).reshape(b * P, -1)
+        rows = np.stack([x[i, idx[i]] for i in range(b)]).reshape(b * n_pos, -1)
         logits = lm_head(sd, rows)
-        toks = odraw.draw_rows(logits, valid_idx, 0, True, 1.0, np.repeat(np.arange(b), P), 0, np.tile(np.arange(P), b), 0, 0)
+        toks = odraw.draw_rows(logits, valid_idx, top_k, sample, 1.0 if sample else None, np.repeat(np.arange(b), n_pos), 0,
+                               np.tile(np.arange(n_pos), b), 0, 0)
         for i in range(b):
-            tok[i, idx[i]] = toks[i * P:(i + 1) * P]
+            tok[i, idx[i]] = toks[i * n_pos:(i + 1) * n_pos]
+        keep["idx"], keep["logits"] = idx, logits
         return time.perf_counter() - t0
 
     t1 = one(1)
     b = int(max(1, min(B, round(target_seconds / max(t1, 1e-3)))))
     t = one(b) if b > 1 else t1
     threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-    return {"value": b * P / t, "unit": "sampled positions/s", "cores": int(threads), "kind": "port",
-            "sample": "%d of %d chains x 1 Gibbs iteration (L=%d, P=%d), fp32 numpy/OpenBLAS oracle, %.1f s" % (b, B, L, P, t)}
+    out = {"value": b * P / t, "unit": "sampled positions/s", "cores": int(threads), "kind": "port",
+           "sample": "%d of %d chains x 1 Gibbs iteration (L=%d, P=%d), fp32 numpy/OpenBLAS oracle, %.1f s" % (b, B, L, P, t)}
+
+    # the oracle as checker: logits of both engine modes at the sampled rows of those b chains
+    check = {"chains": b, "rows": int(b * P), "logit_std": float(keep["logits"].std())}
+    for name, eng in (("bf16", lm), ("fp32", lm_strict)):
+        if eng is None:
+            continue
+        full = eng.forward_logits(keep["masked"])
+        got = np.stack([full[i, keep["idx"][i]] for i in range(b)]).reshape(b * P, -1)
+        check[name + "_max_abs_logit_err"] = float(np.abs(got - keep["logits"]).max())
+    out["logit_check"] = check
+
+    # BASELINE config 1 in full on the CPU: one chain, L = 25, P = 2, 20 iterations (top_k = 1, burnin = 10)
+    t0 = time.perf_counter()
+    for it in range(20):
+        one(1, T_len=25, n_pos=2, top_k=1, sample=it < 10)
+    tc1 = time.perf_counter() - t0
+    out["config1"] = {"cpu_positions_per_s": 40 / tc1, "cpu_ms_per_iter": 1e3 * tc1 / 20,
+                      "workload": "ESM-1b, 1 chain x L=25 (T=27), P=2, 20 iterations, top_k=1, burnin=10, all %d host threads" % threads}
+    if gpu_cfg1:
+        out["config1"].update(gpu_cfg1)
+
+    # reference-style sampling loop: the reference draws position by position in Python (esm_sampler.py:225-234); the
+    # oracle's scalar generate_step stands in for it (one call per sampled position, one core)
+    rows = keep["logits"]
+    n = min(len(rows), 400)
+    t0 = time.perf_counter()
+    for i in range(n):
+        odraw.generate_step(rows, i, temperature=1.0, top_k=0, sample=True, valid_idx=valid_idx, row_id=i, it=0, slot=0, seed=0)
+    per = (time.perf_counter() - t0) / n
+    out["reference_style_position_loop"] = {"us_per_position_one_core": 1e6 * per, "s_per_iteration_at_config2": per * B * P,
+                                            "note": "per-position Python draw loop as in esm_sampler.py:225-234, %d calls timed" % n}
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains-per-gpu", type=int, default=256)
-    ap.add_argument("--length", type=int, default=256)
-    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the JSON then says so)")
-    ap.add_argument("--greedy-after-burnin", action="store_true",
-                    help="SURVEY 8d variant: top_k=1, burnin=25 (argmax after 25 sampled iterations) instead of all-sampling")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    import numpy as np
+    import torch
+    from protein_gibbs_sampler_amd import _lib, models, pyrandom, sharding, weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dry = args.dry_run
+    backend = "gloo" if (dry or args.oversubscribe) else args.backend
+    dev = None
+    if not dry:
+        n_dev = torch.cuda.device_count()
+        if n_dev == 0:
+            raise SystemExit("bench.py needs an MI355X (use --dry-run for the launcher/sharding plumbing check)")
+        if local_rank >= n_dev and not args.oversubscribe:
+            raise SystemExit("rank %d has no GPU (%d visible); --oversubscribe shares GPUs for testing" % (local_rank, n_dev))
+        dev = torch.device("cuda", local_rank % n_dev)
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     cfg = dict(weights.ESM1B_CONFIG)
     if args.layers:
         cfg["n_layers"] = args.layers
-    B, L = args.chains_per_gpu, args.length
+    L = args.length
     T = L + 2
     P = int(L * 10 / 100)
     K, W = args.steps, args.warmup
-    B_total = B * world
+    B_total = args.chains * world if args.weak else args.chains
+    lo, hi = sharding.shard_range(B_total, world, rank)
+    B = hi - lo
+    counts = [sharding.shard_range(B_total, world, r)[1] - sharding.shard_range(B_total, world, r)[0] for r in range(world)]
 
-    sd = weights.synthetic_state_dict(cfg, seed=0)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        wrapper = models.ESM1b(state_dict=sd, config=cfg)
-    lm = wrapper.model.to("cuda:%d" % local_rank)
-    L_ = _lib.lib()
-    valid_idx = sorted(wrapper.alphabet.get_idx(t) for t in "ACDEFGHIKLMNPQRSTVWY")
-
+    valid_idx = list(range(4, 24))                      # ACDEFGHIKLMNPQRSTVWY in the ESM-1b alphabet (sorted ids)
+    top_k, burnin = (1, 25.0) if args.greedy_after_burnin else (0, float("inf"))
     # seeds: B_total chains, L residues i.i.d. uniform over the 20 amino acids, numpy default_rng(1234) (SURVEY 8d)
     rng = np.random.default_rng(1234)
     aa = rng.integers(0, 20, (B_total, L))
-    tok_all = np.concatenate([np.zeros((B_total, 1), np.int64), np.asarray(valid_idx)[aa], np.full((B_total, 1), 2)], axis=1)
-    tok_dev = torch.from_numpy(tok_all[rank * B:(rank + 1) * B].astype(np.int32)).to(dev).contiguous()
-    gathered = None
-
-    pos_rng = pyrandom.NativePyRandom()
-    pos_rng.seed(0)
+    tok_all = np.concatenate([np.zeros((B_total, 1), np.int64), np.asarray(valid_idx)[aa], np.full((B_total, 1), 2)],
+                             axis=1).astype(np.int32)
     population = list(range(1, L + 1))
-    top_k, burnin = (1, 25.0) if args.greedy_after_burnin else (0, float("inf"))
-    params = _lib.make_sample_params(True, cfg["mask_idx"], top_k, burnin, 1.0, valid_idx, rng_seed=0, rng_stream=0,
-                                     row_id_base=rank * B)
-    stream = torch.cuda.current_stream(dev)
-    _lib.check(L_.pg_engine_set_stream(lm.handle, ctypes.c_void_p(stream.cuda_stream)))
 
-    def run(n_iters, iter_base):
-        """n_iters Gibbs iterations: native position table for ALL chains (same stream on every rank), slice, upload, run."""
-        table = sharding.global_position_table(pos_rng, population, P, n_iters, B_total)
-        d_idx = torch.from_numpy(sharding.local_slice(table, rank * B, (rank + 1) * B)).to(dev, non_blocking=True)
-        params.iter_base = iter_base
-        _lib.check(L_.pg_esm_gibbs_run_device(lm.handle, ctypes.c_void_p(tok_dev.data_ptr()), B, T,
-                                              ctypes.c_void_p(d_idx.data_ptr()), n_iters, P, ctypes.byref(params), None, None))
-        return d_idx
+    sd = lm = L_ = None
+    if not dry:
+        sd = weights.synthetic_state_dict(cfg, seed=0)
+        wrapper = models.ESM1b(state_dict=sd, config=cfg, precision=args.precision)
+        lm = wrapper.model.to(str(dev))
+        L_ = _lib.lib()
+        assert valid_idx == sorted(wrapper.alphabet.get_idx(t) for t in "ACDEFGHIKLMNPQRSTVWY")
+        stream = torch.cuda.current_stream(dev)
+        _lib.check(L_.pg_engine_set_stream(lm.handle, ctypes.c_void_p(stream.cuda_stream)))
+
+    class Job:
+        """The Gibbs job on chains [c_lo, c_hi) of the B_total: its own position stream (CPython-exact, seed 0; every rank
+        generates the table for ALL chains and slices its block) and token buffer; run(n) advances n iterations."""
+
+        def __init__(self, engine, c_lo, c_hi):
+            self.engine, self.c_lo, self.c_hi, self.done = engine, c_lo, c_hi, 0
+            self.pos_rng = pyrandom.NativePyRandom()
+            self.pos_rng.seed(0)
+            t = torch.from_numpy(tok_all[c_lo:c_hi].copy())
+            self.tok = t if dry else t.to(dev).contiguous()
+            self.params = _lib.make_sample_params(True, cfg["mask_idx"], top_k, burnin, 1.0, valid_idx, rng_seed=0, rng_stream=0,
+                                                  row_id_base=c_lo)
+
+        def run(self, n_iters):
+            table = sharding.global_position_table(self.pos_rng, population, P, n_iters, B_total)
+            mine = sharding.local_slice(table, self.c_lo, self.c_hi)
+            self.params.iter_base = self.done
+            self.done += n_iters
+            if dry or self.c_hi == self.c_lo:
+                return mine
+            d_idx = torch.from_numpy(mine).to(dev, non_blocking=True)
+            _lib.check(L_.pg_esm_gibbs_run_device(self.engine.handle, ctypes.c_void_p(self.tok.data_ptr()), self.c_hi - self.c_lo, T,
+                                                  ctypes.c_void_p(d_idx.data_ptr()), n_iters, P, ctypes.byref(self.params), None, None))
+            return d_idx                                     # caller keeps it alive until the stream is synchronised
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not dry:
+            torch.cuda.synchronize(dev)
 
+    job = Job(lm, lo, hi)
     if W > 0:
-        keep = run(W, 0)
+        keep = job.run(W)
     barrier()
     t0 = time.perf_counter()
-    keep = run(K, W)                                                   # noqa: F841 (keeps the index table alive)
+    keep = job.run(K)                                                  # noqa: F841
+    gathered = None
     if dist is not None:
-        lm.synchronize()                                               # engine stream -> before the collective reads tokens
-        gathered = sharding.gather_tokens(dist, tok_dev)               # the one collective: final token buffers
+        if not dry:
+            lm.synchronize()                                           # engine stream -> before the collective reads the tokens
+        src = job.tok.cpu() if (backend == "gloo" and not dry) else job.tok
+        gathered = sharding.gather_tokens(dist, src, counts)           # the one collective: final token buffers
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    final = (gathered if gathered is not None else tok_dev).cpu().numpy()
-    assert ((final[:, 1:-1] >= 4) & (final[:, 1:-1] <= 23)).all(), "chains left the 20-amino-acid alphabet"
+    final = (gathered if gathered is not None else job.tok).cpu().numpy()
+    assert final.shape == (B_total, T)
+    if not dry:
+        assert ((final[:, 1:-1] >= 4) & (final[:, 1:-1] <= 23)).all(), "chains left the 20-amino-acid alphabet"
 
-    value = B_total * P * K / elapsed
-    out = {"metric": "sampled positions/sec (whole node), ESM-1b L=256 B=256 Gibbs", "value": value,
+    mode = "bf16" if args.precision == "bf16" else "bf16x3"
+    out = {"metric": "sampled positions/sec (whole node), ESM-1b L=256 B=256 Gibbs", "value": B_total * P * K / elapsed,
            "unit": "sampled positions/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "ESM_sampler ESM-1b (33 layers, d=1280) Gibbs: %d chains/GPU x L=%d (T=%d), P=%d positions "
-                                  "per chain per iteration, mask=True top_k=%d temperature=1.0 burnin=%s; bf16 MFMA "
-                                  "operands, fp32 accumulate + fp32 residual stream; synthetic N(0,0.02) weights"
-                                  % (B, L, T, P, top_k, "inf" if burnin == float("inf") else int(burnin)),
-                      "global_batch": B_total, "seq_len": L, "parallelism": "chains sharded %d-way, 1 RCCL all-gather at end" % world,
-                      "n_layers": cfg["n_layers"]}}
+           "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": mode,
+           "data": "synthetic",
+           "config": {"workload": "ESM_sampler ESM-1b (33 layers, d=1280) Gibbs: %d chains in total, %s per GPU x L=%d (T=%d), P=%d "
+                                  "positions per chain per iteration, mask=True top_k=%d temperature=1.0 burnin=%s; %s; "
+                                  "synthetic N(0,0.02) weights"
+                                  % (B_total, "/".join(str(c) for c in sorted(set(counts))), L, T, P, top_k,
+                                     "inf" if burnin == float("inf") else int(burnin),
+                                     "bf16 MFMA operands, fp32 accumulate + fp32 residual stream" if args.precision == "bf16"
+                                     else "strict mode: split-bf16 x3 MFMA GEMMs, fp32 attention/softmax/LayerNorm"),
+                      "global_batch": B_total, "seq_len": L,
+                      "parallelism": "chains sharded %d-way (contiguous blocks), 1 %s all-gather at the end"
+                                     % (world, "RCCL" if backend == "nccl" else "gloo"),
+                      "n_layers": cfg["n_layers"]},
+           "ranks_seen": dist.get_world_size() if dist is not None else 1, "backend": backend if dist is not None else None}
+    if dry:
+        out["dry_run"] = True
+        out["value"] = 0.0
+        # plumbing check: every rank's table slice equals the single-stream table, the gather restores the chain order
+        random_ok = bool((final == tok_all).all())
+        assert random_ok, "gather changed the chain order"
+        out["verified_vs_single_gpu"] = random_ok
 
-    if rank == 0:
+    # ---- N > 1: the gathered tokens must equal the single-GPU result bit for bit (rank 0, outside the timed region) ----
+    if not dry and dist is not None and not args.no_verify:
+        if rank == 0:
+            ref = Job(lm, 0, B_total)
+            if W > 0:
+                k2 = ref.run(W)
+            k3 = ref.run(K)                                            # noqa: F841
+            torch.cuda.synchronize(dev)
+            same = bool((ref.tok.cpu().numpy() == final).all())
+            out["verified_vs_single_gpu"] = same
+            assert same, "sharded result differs from the single-GPU result"
+        dist.barrier()
+
+    if rank == 0 and not dry:
         n_tok, n_samp = B * T, B * P
-        flops_iter = total_flops_per_iter(cfg, n_tok, T, n_samp)
-        out["model_tflops_per_gpu"] = flops_iter * K / elapsed / 1e12
-        out["frac_of_bf16_mfma_peak"] = out["model_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS
-    if not args.no_roofline:
+        flops_iter = total_flops_per_iter(cfg, n_tok, T, n_samp) * (3 if args.precision == "fp32" else 1)
+        out["model_tflops_per_gpu"] = total_flops_per_iter(cfg, n_tok, T, n_samp) * K / elapsed / 1e12
+        out["executed_tflops_per_gpu"] = flops_iter * K / elapsed / 1e12
+        out["frac_of_bf16_mfma_peak"] = out["executed_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS
+    if not dry and not args.no_roofline:
         # dominant kernel family = the bf16 MFMA GEMM; HIP events on the engine's stream around every launch
         lm.prof_enable(True)
         lm.prof_reset()
         n_prof = min(K, 3)
-        run(n_prof, W + K)
+        keep = job.run(n_prof)
         torch.cuda.synchronize(dev)
         ms, launches = lm.prof_get("gemm")
         parts = {c: lm.prof_get(c) for c in ("gemm", "attention", "layernorm", "embed", "head", "sample")}
         lm.prof_enable(False)
-        if rank == 0 and launches:
+        if rank == 0 and launches and args.precision == "bf16":
             # FLOPs the GEMM launches actually executed: every layer on all B*T rows, except that the last layer's
             # out-proj / fc1 / fc2 run on the B*P sampled rows only (exact pruning, DESIGN.md); head GEMM timed under "head"
             d_, f_, nl_ = cfg["d_model"], cfg["d_ffn"], cfg["n_layers"]
@@ -220,15 +359,57 @@ def main():
             last = 2.0 * (3 * d_ * d_) * (B * T) + 2.0 * (d_ * d_ + 2 * d_ * f_) * (B * P)
             gf = ((nl_ - 1) * full + last) * n_prof
             achieved = gf / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel (all %d launches/iteration)" % (launches // n_prof),
+            traffic, traffic_src = measured_gemm_traffic()
+            out["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (all %d launches/iteration)" % (launches // n_prof),
                                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_gemm_traffic(),
-                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated), avg over the 4 per-layer GEMMs; "
-                                               "algorithmic minimum 0.63 GB/launch -- the excess is X/W panel re-reads served by the 256 MB Infinity Cache",
+                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated; %s), avg over the per-layer "
+                                               "GEMMs; algorithmic minimum 0.63 GB/launch" % traffic_src,
                                "avg_launch_ms": ms / launches, "flops_per_launch": gf / launches}
+        if rank == 0:
             out["time_split_ms_per_iter"] = {c: v[0] / n_prof for c, v in parts.items()}
-    if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, sd, B, L, P, valid_idx)
+
+    # ---- N = 1 extras: strict-mode leg, config 1 on the GPU, CPU baseline ------------------------------------------------
+    lm_strict = None
+    if rank == 0 and world == 1 and not dry and args.precision == "bf16" and not args.no_strict:
+        lm_strict = models.ESM1b(state_dict=sd, config=cfg, precision="fp32").model.to(str(dev))
+        _lib.check(L_.pg_engine_set_stream(lm_strict.handle, ctypes.c_void_p(stream.cuda_stream)))
+        sj = Job(lm_strict, 0, B_total)
+        keep = sj.run(1)
+        torch.cuda.synchronize(dev)
+        ks = max(1, min(K, 3))
+        t0 = time.perf_counter()
+        keep = sj.run(ks)
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter() - t0
+        out["strict_mode"] = {"value": B_total * P * ks / ts, "unit": "sampled positions/s", "ms_per_step": 1e3 * ts / ks, "steps": ks,
+                              "precision": "PG_PREC_FP32: split-bf16 x3 MFMA GEMMs (hi.hi + hi.lo + lo.hi), fp32 attention",
+                              "max_abs_logit_err": None}
+    gpu_cfg1 = None
+    if rank == 0 and world == 1 and not dry and not args.no_cpu_baseline:
+        # BASELINE config 1 on the GPU: one chain, L = 25 (T = 27), P = 2, 20 iterations, top_k = 1, burnin = 10
+        import random
+        from protein_gibbs_sampler_amd import esm_sampler
+        s1 = esm_sampler.ESM_sampler(wrapper, device=str(dev))
+        kw = dict(batch_size=1, num_iters=20, burnin=10, mask=True, in_order=False, num_positions_percent=10, top_k=1,
+                  show_progress_bar=False)
+        random.seed(0)
+        s1.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", **kw)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            s1.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", **kw)
+        tg = (time.perf_counter() - t0) / 5
+        gpu_cfg1 = {"gpu_positions_per_s": 40 / tg, "gpu_ms_per_iter": 1e3 * tg / 20}
+        _lib.check(L_.pg_engine_set_stream(lm.handle, ctypes.c_void_p(stream.cuda_stream)))
+    if rank == 0 and world == 1 and not dry and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, lm if args.precision == "bf16" else None,
+                                           lm_strict if lm_strict is not None else (lm if args.precision == "fp32" else None),
+                                           B_total, L, P, valid_idx, gpu_cfg1)
+        chk = out["cpu_baseline"]["logit_check"]
+        if "strict_mode" in out:
+            out["strict_mode"]["max_abs_logit_err"] = chk.get("fp32_max_abs_logit_err")
+            out["strict_mode"]["logit_std"] = chk["logit_std"]
+        out["bf16_max_abs_logit_err"] = chk.get("bf16_max_abs_logit_err")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

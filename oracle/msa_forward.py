@@ -18,11 +18,13 @@ algorithm:
 
 PARITY UNPINNED: the reference's numeric KATs for this boundary
 (/root/reference/test/test_esm_msa_sampler.py:248-397, 561-565) need the pretrained
-esm_msa1b_t12_100M_UR50S checkpoint, unavailable offline, and no independent implementation exists
-here.  The restatement is checked by the invariants fair-esm's own code relies on
-(tests/test_oracle_msa.py): R == 1 column-attention shortcut, row-permutation equivariance,
-independence of MSAs in a batch, and agreement of the shared sub-blocks (embedding, LayerNorm, FFN,
-LM head) with the HF-corroborated ESM-1b oracle.
+esm_msa1b_t12_100M_UR50S checkpoint, unavailable offline, and no third-party implementation exists
+here.  The restatement is checked (tests/test_oracle_msa.py) by the invariants fair-esm's own code
+relies on -- R == 1 column-attention shortcut, row-permutation equivariance, independence of MSAs in a
+batch, agreement of the shared sub-blocks (embedding, LayerNorm, FFN, LM head) with the
+HF-corroborated ESM-1b oracle -- and against tests/_msa_alt.py, a second restatement written in
+fair-esm's own R x C x B x D layout with its einsum strings ("rinhd,rjnhd->hnij", "icnhd,jcnhd->hcnij")
+in torch, including fair-esm's chunked `max_tokens_per_msa` paths (chunked == unchunked).
 """
 import numpy as np
 

@@ -27,8 +27,11 @@ def parse_line_args(text):
 
 
 def add_engine_args(parser):
-    parser.add_argument("--checkpoint", default=None, help="fair-esm .pt checkpoint to load (default: torch hub cache, else "
-                        "seeded synthetic weights with a warning)")
+    parser.add_argument("--checkpoint", default=None, help="fair-esm .pt checkpoint to load (default: torch hub cache; it is an "
+                        "error if none is found)")
+    parser.add_argument("--synthetic-weights", dest="synthetic_weights", action="store_true",
+                        help="opt in to seeded random weights of the model's architecture when no checkpoint is available "
+                             "(benchmarks / plumbing tests: the output is not biologically meaningful)")
     parser.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                         help="bf16 = throughput mode; fp32 = parity mode (split-bf16 GEMMs, fp32 attention)")
     parser.add_argument("--seed", type=int, default=None, help="seed random and torch (positions and token draws) for reproducible output")

@@ -12,6 +12,59 @@ from . import pyrandom as _pyr
 SHADOW_BIT = 1 << 30   # include/pgibbs.h: sampled but not written (a later duplicate in the same row wins)
 
 
+def resolve_device(device):
+    """The reference's device grammar (esm_sampler.py:66-78, esm_msa_sampler.py:47-61): "cpu" | "gpu" | "cuda:N", with
+    its three error messages.  Returns (device string, uses_gpu)."""
+    import re
+
+    import torch
+    if device == "gpu":
+        device = "cuda:0"
+    if re.match("^cuda:[0-9]+$", device):
+        if not torch.cuda.is_available():
+            raise Exception("gpu requested, but No Cuda devices found")
+        if int(device.split(":")[1]) >= torch.cuda.device_count():
+            raise Exception("Invalid cuda device number: " + device)
+        return device, True
+    if device != "cpu":
+        raise Exception("Invalid device: " + device)
+    return device, False
+
+
+def clean_seed(seq, allowed):
+    """clean_seed_seq of both samplers (esm_sampler.py:95-102, esm_msa_sampler.py:93-99)."""
+    seq = seq.upper()
+    bad = set(seq) - set(allowed)
+    if bad:
+        raise Exception("Invalid input character: " + ",".join(bad))
+    return seq
+
+
+def mask_padded(seq, max_len, allowed):
+    """A cleaned seed right-padded with the literal "<mask>" up to max_len residues (esm_sampler.py:115,120)."""
+    return clean_seed(seq, allowed) + "<mask>" * (max_len - len(seq))
+
+
+def candidate_indexes(indexes, leader_length, max_len, rollover_from_start):
+    """calculate_indexes (esm_sampler.py:264-274, esm_msa_sampler.py:294-304): 1-based token positions after the leader
+    (position 0 is <cls>), or the caller's `indexes` untouched; last_i = where an in-order sweep starts."""
+    if indexes is not None:
+        return indexes, -1
+    indexes = range(1, max_len + 1)
+    if rollover_from_start:
+        return indexes, -1
+    return indexes[leader_length:], leader_length - 1
+
+
+def derive_counts(length, num_positions, num_positions_percent, leader_length, leader_length_percent):
+    """num_positions / leader_length from their *_percent forms, clamped at 0 (esm_sampler.py:189-197)."""
+    if num_positions_percent is not None:
+        num_positions = int(length * (num_positions_percent / 100))
+    if leader_length_percent is not None:
+        leader_length = int(length * (leader_length_percent / 100))
+    return max(num_positions, 0), max(leader_length, 0)
+
+
 def in_order_window(indexes, next_i, num_positions):
     """get_target_index_in_order (/root/reference/src/pgen/esm_sampler.py:248-257)."""
     out = []
@@ -20,6 +73,24 @@ def in_order_window(indexes, next_i, num_positions):
         next_i = (next_i + 1) % n
         out.append(indexes[next_i])
     return next_i, out
+
+
+def normalise_indexes(indexes, width):
+    """Candidate positions as the reference's `batch[b][kk]` would resolve them (esm_sampler.py:234,262): a torch row of
+    `width` tokens accepts -width <= kk < width, negative values counting from the end; anything else is the IndexError
+    torch raises there.  `range` objects (the default candidates) are returned untouched."""
+    if isinstance(indexes, range):
+        if len(indexes) and (indexes[0] < -width or indexes[-1] >= width or indexes[0] < 0):
+            indexes = list(indexes)
+        else:
+            return indexes
+    out = []
+    for kk in indexes:
+        k = int(kk)
+        if k < -width or k >= width:
+            raise IndexError("index %d is out of bounds for dimension 0 with size %d" % (k, width))
+        out.append(k + width if k < 0 else k)
+    return out
 
 
 def mark_shadowed(table, indexes):

@@ -28,6 +28,23 @@ int check_params(const pg_sample_params* p) {
   if (p->n_valid < 1 || p->n_valid > 32) return fail(PG_ERR_INVALID, "n_valid must be in 1..32");
   return PG_OK;
 }
+
+// host-side index tables: entries < 0 are padding; bit 30 marks a shadowed duplicate; the position itself must lie inside the
+// token row (the reference raises IndexError there: batch[b][kk] = ..., esm_sampler.py:234,262)
+int check_idx_table(const int32_t* idx, size_t n, int width, const char* who) {
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t v = idx[i];
+    if (v >= 0 && (v & 0x3fffffff) >= width)
+      return fail(PG_ERR_INVALID, std::string(who) + ": target position " + std::to_string(v & 0x3fffffff) +
+                                      " is out of range for a token row of width " + std::to_string(width));
+  }
+  return PG_OK;
+}
+bool has_token(const int32_t* tokens, size_t n, int32_t id) {
+  for (size_t i = 0; i < n; ++i)
+    if (tokens[i] == id) return true;
+  return false;
+}
 }  // namespace
 
 extern "C" {
@@ -121,6 +138,10 @@ int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const in
   DeviceGuard g(e.device);
   const size_t tok_bytes = (size_t)B * T * 4;
   const size_t n_draws = (size_t)B * P * n_iters;
+  if (n_draws && (rc = check_idx_table(target_idx, n_draws, T, "pg_esm_gibbs_run"))) return rc;
+  // a ragged batch (<pad> in some row): keys at <pad> are masked in attention, as fair-esm's key_padding_mask does
+  struct PadFlag { Engine& e; ~PadFlag() { e.esm_pad_in_batch = false; } } pad_reset{e};
+  e.esm_pad_in_batch = has_token(tokens_inout, (size_t)B * T, e.cfg.pad_idx);
   if ((rc = e.d_tokens.ensure(tok_bytes, e.stream))) return rc;
   if ((rc = e.d_idx.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
   if (sampled_logits && (rc = e.d_samp_logits.ensure((n_draws ? n_draws : 1) * e.cfg.vocab * 4, e.stream))) return rc;
@@ -171,6 +192,7 @@ int pg_msa_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int R, int C, c
   DeviceGuard g(e.device);
   const size_t tok_bytes = (size_t)B * R * C * 4;
   const size_t n_draws = (size_t)B * R * P * n_iters;
+  if (n_draws && (rc = check_idx_table(target_idx, n_draws, C, "pg_msa_gibbs_run"))) return rc;
   if ((rc = e.d_tokens.ensure(tok_bytes, e.stream))) return rc;
   if ((rc = e.d_idx.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
   if (sampled_logits && (rc = e.d_samp_logits.ensure((n_draws ? n_draws : 1) * e.cfg.vocab * 4, e.stream))) return rc;
@@ -202,6 +224,7 @@ int pg_msa_gibbs_single_run(pg_engine* h, int32_t* tokens_inout, int R, int C, i
   DeviceGuard g(e.device);
   const size_t tok_bytes = (size_t)R * C * 4;
   const size_t n_draws = (size_t)P_max * n_steps;
+  if (n_draws && (rc = check_idx_table(step_idx, n_draws, C, "pg_msa_gibbs_single_run"))) return rc;
   if ((rc = e.d_tokens.ensure(tok_bytes, e.stream))) return rc;
   if ((rc = e.d_idx.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
   if (sampled_logits && (rc = e.d_samp_logits.ensure((n_draws ? n_draws : 1) * e.cfg.vocab * 4, e.stream))) return rc;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __rest
   const int nch4 = d >> 2;
   int pos = idx ? idx[r] : 0;
   float4 v[kMaxCh];
-  if (pos < 0) {
+  if (pos < 0 || (idx && (pos & 0x3fffffff) >= width)) {
 #pragma unroll
     for (int i = 0; i < kMaxCh; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restric
   if (d_iter) idx += (size_t)(*d_iter) * n_sel;
   int pos = idx[r];
   pos = pos < 0 ? 0 : (pos & 0x3fffffff);
+  if (pos >= width) pos = 0;          // out-of-range entries are never sampled (sample_writeback_kernel skips them)
   const int64_t s = r / P;
   const int64_t row = (row_map ? (int64_t)row_map[s] : s) * width + pos;
   for (int c = threadIdx.x & 63; c < chunks; c += 64) dst[r * chunks + c] = src[row * chunks + c];

@@ -417,7 +417,7 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
     pg_sample_params k = *sp;          // every field is baked into the captured kernel arguments (incl. iter_base)
     memcpy(key.data(), &k, sizeof(k));
     const int64_t dims[7] = {(int64_t)(uintptr_t)d_tok, (int64_t)(uintptr_t)d_idx_, B, T, P, (int64_t)(uintptr_t)stream,
-                             (int64_t)g_alloc_epoch};
+                             (int64_t)(g_alloc_epoch * 2 + (esm_pad_in_batch ? 1 : 0))};
     memcpy(key.data() + sizeof(k), dims, sizeof(dims));
   }
   if (!graph_exec || key != graph_key) {

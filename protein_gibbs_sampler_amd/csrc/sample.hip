@@ -89,6 +89,10 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
     return;
   }
   const int pos = raw & 0x3fffffff;
+  if (pos >= width) {          // out-of-range position (the host entry points reject these; *_device callers are guarded here)
+    if (sampled_tokens) sampled_tokens[i] = -1;
+    return;
+  }
   const int64_t trow = row_map ? (int64_t)row_map[s] : s;
   const float* row = compact ? logits + (size_t)i * V : logits + ((size_t)trow * width + pos) * V;
 
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(int32_t* __restrict__
   if (i >= n_sel * P) return;
   if (d_iter) idx += (size_t)(*d_iter) * n_sel * P;
   const int raw = idx[i];
-  if (raw < 0) return;
+  if (raw < 0 || (raw & 0x3fffffff) >= width) return;
   const int64_t s = i / P;
   const int64_t trow = row_map ? (int64_t)row_map[s] : s;
   tokens[trow * width + (raw & 0x3fffffff)] = mask_idx;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void logprob_gather_kernel(const float* __rest
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_sel * P) return;
   const int pos = idx[i];
-  if (pos < 0) { out[i] = 0.f; return; }
+  if (pos < 0 || pos >= width) { out[i] = 0.f; return; }
   const int64_t s = i / P;
   const int64_t trow = row_map ? (int64_t)row_map[s] : s;
   const float* row = compact ? logits + (size_t)i * V : logits + ((size_t)trow * width + pos) * V;

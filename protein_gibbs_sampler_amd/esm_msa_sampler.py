@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from tqdm import trange
 
-from . import _gibbs, _lib
+from . import _gibbs, _lib, sharding
 from .engine import NativeMaskedLM
 from .esm_sampler import generate_step  # noqa: F401  (same re-export as the reference, :6)
 
@@ -44,20 +44,7 @@ class ESM_MSA_sampler():
     def __init__(self, model, device="cpu"):
         self.model = model
         self.model.model = self.model.model.eval()
-        self.cuda = False
-        self.device = device
-        if self.device == "gpu":
-            self.device = "cuda:0"
-        if re.match("^cuda:[0-9]+$", self.device):
-            cuda_device_num = int(self.device.split(":")[1])
-            if torch.cuda.is_available():
-                self.cuda = True
-            else:
-                raise Exception("gpu requested, but No Cuda devices found")
-            if cuda_device_num >= torch.cuda.device_count():
-                raise Exception("Invalid cuda device number: " + self.device)
-        elif self.device != "cpu":
-            raise Exception("Invalid device: " + self.device)
+        self.device, self.cuda = _gibbs.resolve_device(device)
         self.model.model.to(self.device)
         self.valid_aa_idx = sorted([self.model.alphabet.get_idx(tok) for tok in ESM_MSA_ALLOWED_AMINO_ACIDS])
         self.toks = [self.model.alphabet.get_tok(idx) for idx in self.valid_aa_idx]
@@ -65,6 +52,7 @@ class ESM_MSA_sampler():
         self.rng_stream = 0
         self.record = False
         self.last_run = []
+        self.shard_over_ranks = True     # several torch.distributed ranks: generate() splits the MSAs of a batch over them
 
     def untokenize_batch(self, batch):
         if hasattr(batch, "tolist"):
@@ -75,21 +63,12 @@ class ESM_MSA_sampler():
         return out_batch
 
     def get_init_msa(self, seed_msa, max_len, batch_size=1):
-        padded_msa = list()
-        for i, seq in enumerate(seed_msa):
-            seq = self.clean_seed_seq(seq)
-            remaining_len = max_len - len(seq)
-            padded_msa.append((str(i), seq + "<mask>" * remaining_len))
-        labels, strs, tokens = self.model.batch_converter([padded_msa] * batch_size)
-        return tokens
+        """[B, R, C] tokens: every row <mask>-padded to max_len, the MSA repeated batch_size times (reference :78-90)."""
+        rows = [(str(i), _gibbs.mask_padded(seq, max_len, ESM_MSA_ALLOWED_AMINO_ACIDS)) for i, seq in enumerate(seed_msa)]
+        return self.model.batch_converter([rows] * batch_size)[2]
 
     def clean_seed_seq(self, seq):
-        seq = seq.upper()
-        input_chars = {s for s in seq}
-        valid_chars = {s for s in ESM_MSA_ALLOWED_AMINO_ACIDS}
-        if not input_chars.issubset(valid_chars):
-            raise (Exception("Invalid input character: " + ",".join(input_chars - valid_chars)))
-        return seq
+        return _gibbs.clean_seed(seq, ESM_MSA_ALLOWED_AMINO_ACIDS)
 
     def _require_gpu(self, what):
         if not self.cuda:
@@ -109,6 +88,8 @@ class ESM_MSA_sampler():
         positions = [x for x in range(1, sequence_length + 1) if x not in exclude_positions]
         batch = self.get_init_msa(seed_msa, len(seed_msa[0]), 1)
         R = batch.shape[1]
+        if not -R <= target_index < R:
+            raise IndexError("index %d is out of bounds for dimension 0 with size %d" % (target_index, R))
 
         # the step lists of every pass, decided up front (selection never depends on the logits)
         from . import pyrandom
@@ -147,24 +128,23 @@ class ESM_MSA_sampler():
         sequence_length = len(seed_msa[0])
         sequences = []
         n_generation_rounds = math.ceil(n_samples / num_sequences / batch_size)
-        if num_positions_percent is not None:
-            num_positions = int(sequence_length * (num_positions_percent / 100))
-        if num_positions < 0:
-            num_positions = 0
-        if leader_length_percent is not None:
-            leader_length = int(sequence_length * (leader_length_percent / 100))
-        if leader_length < 0:
-            leader_length = 0
+        num_positions, leader_length = _gibbs.derive_counts(sequence_length, num_positions, num_positions_percent,
+                                                            leader_length, leader_length_percent)
         if max_len is None:
             max_len = sequence_length
         self._require_gpu("generate")
         draw_seed = self._draw_seed()
         native = isinstance(self.model.model, NativeMaskedLM)
         self.last_run = []
+        ctx = sharding.dist_context() if (native and self.shard_over_ranks) else None
+        if ctx is not None:
+            sharding.sync_host_rng(ctx)
+            draw_seed = sharding.broadcast_object(ctx, draw_seed)
 
         for generation_round in trange(n_generation_rounds, disable=(not show_progress_bar)):
             batch = self.get_init_msa(seed_msa, max_len, batch_size)        # [B, R, C]
             indexes, last_i = self.calculate_indexes(indexes, leader_length, max_len, rollover_from_start)
+            indexes = _gibbs.normalise_indexes(indexes, batch.shape[2])
             if num_positions > len(indexes):
                 num_positions = len(indexes)
             table, last_i = _gibbs.build_target_table(num_iters, (batch_size, num_sequences), indexes, num_positions,
@@ -172,7 +152,16 @@ class ESM_MSA_sampler():
             params = _lib.make_sample_params(mask, self.model.alphabet.mask_idx, top_k, burnin, temperature,
                                              self.valid_aa_idx, draw_seed, rng_stream=self.rng_stream,
                                              row_id_base=generation_round * batch_size * num_sequences)
-            if native:
+            if native and ctx is not None:
+                def run_block(ltok, ltable, base):
+                    params.row_id_base = base & 0xFFFFFFFF
+                    self.model.model.gibbs_run(ltok, ltable, params)
+                tok = sharding.run_sharded(ctx, np.ascontiguousarray(batch.numpy(), dtype=np.int32), table,
+                                           generation_round * batch_size * num_sequences, num_sequences, run_block, self.device)
+                batch = torch.from_numpy(tok.astype(np.int64))
+                if self.record:
+                    self.last_run.append(dict(table=table, tokens=tok.copy()))
+            elif native:
                 tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)
                 lg, st = self.model.model.gibbs_run(tok, table, params, want_logits=self.record, want_tokens=self.record)
                 batch = torch.from_numpy(tok.astype(np.int64))
@@ -213,16 +202,8 @@ class ESM_MSA_sampler():
         return last_i, [[per_seq] * num_sequences for _ in range(batch_size)]
 
     def calculate_indexes(self, indexes, leader_length, max_len, rollover_from_start):
-        if indexes is None:
-            indexes = list(range(1, max_len + 1))
-            if not rollover_from_start:
-                indexes = indexes[leader_length:]
-                last_i = leader_length - 1
-            else:
-                last_i = -1
-        else:
-            last_i = -1
-        return indexes, last_i
+        indexes, last_i = _gibbs.candidate_indexes(indexes, leader_length, max_len, rollover_from_start)
+        return (list(indexes) if isinstance(indexes, range) else indexes), last_i     # the MSA sampler hands out a list (:296)
 
     # ---- masked log-likelihood of one MSA row (reference :306-432) --------------------------------------
     def log_likelihood(self, msa, target_index=0, with_masking=True, verbose=False, count_gaps=False,

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from tqdm import trange
 
-from . import _gibbs, _lib
+from . import _gibbs, _lib, sharding
 from .engine import NativeMaskedLM
 
 ESM_ALLOWED_AMINO_ACIDS = "ACDEFGHIKLMNPQRSTVWY"
@@ -79,20 +79,7 @@ class ESM_sampler():
         """model: an object with attributes model, alphabet and batch_converter (reference :54-58)."""
         self.model = model
         self.model.model = self.model.model.eval()
-        self.cuda = False
-        self.device = device
-        if self.device == "gpu":
-            self.device = "cuda:0"
-        if re.match("^cuda:[0-9]+$", self.device):
-            cuda_device_num = int(self.device.split(":")[1])
-            if torch.cuda.is_available():
-                self.cuda = True
-            else:
-                raise Exception("gpu requested, but No Cuda devices found")
-            if cuda_device_num >= torch.cuda.device_count():
-                raise Exception("Invalid cuda device number: " + self.device)
-        elif self.device != "cpu":
-            raise Exception("Invalid device: " + self.device)
+        self.device, self.cuda = _gibbs.resolve_device(device)
         self.model.model.to(self.device)
         self.valid_aa_idx = sorted([self.model.alphabet.get_idx(tok) for tok in ESM_ALLOWED_AMINO_ACIDS])
         # key of the token-draw generator; None -> drawn from torch's global RNG once per generate()
@@ -101,6 +88,8 @@ class ESM_sampler():
         # filled by generate(..., ) when self.record is True: per-batch dicts with tables / sampled logits / tokens
         self.record = False
         self.last_run = []
+        # when torch.distributed is initialised with several ranks, generate() shards each batch over them
+        self.shard_over_ranks = True
 
     # ---- helpers with the reference's names ----------------------------------------------------
     def untokenize_batch(self, batch, bos, eos):
@@ -113,28 +102,19 @@ class ESM_sampler():
 
     @staticmethod
     def clean_seed_seq(seed_to_clean):
-        cleaned_seq = seed_to_clean.upper()
-        input_chars = {s for s in cleaned_seq}
-        valid_chars = {s for s in ESM_ALLOWED_AMINO_ACIDS}
-        if not input_chars.issubset(valid_chars):
-            raise (Exception("Invalid input character: " + ",".join(input_chars - valid_chars)))
-        return cleaned_seq
+        return _gibbs.clean_seed(seed_to_clean, ESM_ALLOWED_AMINO_ACIDS)
 
     def get_init_seq(self, seed_seq, max_len, batch_size=1):
-        """Get initial sequence by padding seed_seq with masks (reference :104-126)."""
+        """Initial token batch: seeds right-padded with <mask> (reference :104-126).  A list of seeds consumes the
+        interpreter's RNG once per batch (random.choices, :112) BEFORE any position draw."""
         if isinstance(seed_seq, list):
-            batch = random.choices(seed_seq, k=batch_size)
-            for i, seed in enumerate(batch):
-                remaining_len = max_len - len(seed)
-                batch[i] = (str(i), self.clean_seed_seq(seed) + "<mask>" * remaining_len)
+            seeds = random.choices(seed_seq, k=batch_size)
         elif isinstance(seed_seq, str):
-            remaining_len = max_len - len(seed_seq)
-            seed_seq = self.clean_seed_seq(seed_seq)
-            batch = [(str(i), seed_seq + "<mask>" * remaining_len) for i in range(batch_size)]
+            seeds = [seed_seq] * batch_size
         else:
-            raise (Exception("seed sequence should either be a string or list"))
-        labels, strs, tokens = self.model.batch_converter(batch)
-        return tokens
+            raise Exception("seed sequence should either be a string or list")
+        rows = [(str(i), _gibbs.mask_padded(seed, max_len, ESM_ALLOWED_AMINO_ACIDS)) for i, seed in enumerate(seeds)]
+        return self.model.batch_converter(rows)[2]
 
     def get_random_target_index(self, batch_size, indexes, num_positions):
         """== [random.sample(indexes, num_positions) for b in range(batch_size)] (reference :242-246),
@@ -169,16 +149,7 @@ class ESM_sampler():
                 batch[batch_index][kk] = mask_idx
 
     def calculate_indexes(self, indexes, leader_length, max_len, rollover_from_start):
-        if indexes is None:
-            indexes = range(1, max_len + 1)  # skip position 0: <cls>
-            if not rollover_from_start:
-                indexes = indexes[leader_length:]
-                last_i = leader_length - 1
-            else:
-                last_i = -1
-        else:
-            last_i = -1
-        return indexes, last_i
+        return _gibbs.candidate_indexes(indexes, leader_length, max_len, rollover_from_start)
 
     # ---- the sampler -----------------------------------------------------------------------------
     def generate(self, n_samples, seed_seq, batch_size=1, in_order=False, max_len=None, leader_length=0,
@@ -197,14 +168,8 @@ class ESM_sampler():
         n_batches = math.ceil(n_samples / batch_size)
         if max_len is None:
             max_len = sequence_length
-        if num_positions_percent is not None:
-            num_positions = int(max_len * (num_positions_percent / 100))
-        if num_positions < 0:
-            num_positions = 0
-        if leader_length_percent is not None:
-            leader_length = int(max_len * (leader_length_percent / 100))
-        if leader_length < 0:
-            leader_length = 0
+        num_positions, leader_length = _gibbs.derive_counts(max_len, num_positions, num_positions_percent, leader_length,
+                                                            leader_length_percent)
 
         if not self.cuda:
             raise RuntimeError("ESM_sampler.generate needs device 'gpu'/'cuda:N' on an MI355X: this package implements the "
@@ -212,18 +177,33 @@ class ESM_sampler():
         draw_seed = self.draw_seed if self.draw_seed is not None else int(torch.randint(0, 2**62, (1,)).item())
         native = isinstance(self.model.model, NativeMaskedLM)
         self.last_run = []
+        # several torch.distributed ranks (one per GPU): every batch is split contiguously over them
+        ctx = sharding.dist_context() if (native and self.shard_over_ranks) else None
+        if ctx is not None:
+            sharding.sync_host_rng(ctx)
+            draw_seed = sharding.broadcast_object(ctx, draw_seed)
 
         for batch_n in trange(n_batches, disable=(not show_progress_bar)):
             batch = self.get_init_seq(seed_seq, max_len, batch_size)
 
             indexes, last_i = self.calculate_indexes(indexes, leader_length, max_len, rollover_from_start)
+            indexes = _gibbs.normalise_indexes(indexes, batch.shape[1])     # IndexError / negative wrap as batch[b][kk]
             if num_positions > len(indexes):
                 num_positions = len(indexes)
 
             table, last_i = _gibbs.build_target_table(num_iters, (batch_size,), indexes, num_positions, in_order, last_i)
             params = _lib.make_sample_params(mask, self.model.alphabet.mask_idx, top_k, burnin, temperature, self.valid_aa_idx,
                                              draw_seed, rng_stream=self.rng_stream, row_id_base=batch_n * batch_size)
-            if native:
+            if native and ctx is not None:
+                def run_block(ltok, ltable, base):
+                    params.row_id_base = base & 0xFFFFFFFF
+                    self.model.model.gibbs_run(ltok, ltable, params)
+                tok = sharding.run_sharded(ctx, np.ascontiguousarray(batch.numpy(), dtype=np.int32), table,
+                                           batch_n * batch_size, 1, run_block, self.device)
+                batch = torch.from_numpy(tok.astype(np.int64))
+                if self.record:
+                    self.last_run.append(dict(table=table, tokens=tok.copy()))
+            elif native:
                 tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)
                 lg, st = self.model.model.gibbs_run(tok, table, params, want_logits=self.record, want_tokens=self.record)
                 batch = torch.from_numpy(tok.astype(np.int64))

@@ -72,7 +72,7 @@ def cli(argv=None):
         raise ValueError("mask distance must be an integer >= 1.")
     if args.masking_off and args.mask_distance is not None:
         raise ValueError("--masking_off and --mask_distance are both set, that doesn't make sense.")
-    sampler = ESM_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision), device=args.device)
+    sampler = ESM_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision, synthetic=args.synthetic_weights), device=args.device)
     input_handle = open(args.i) if args.i is not None else sys.stdin
     output_handle = open(args.o, "w") if args.o is not None else sys.stdout
     try:

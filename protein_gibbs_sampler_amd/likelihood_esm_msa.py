@@ -134,7 +134,7 @@ def cli(argv=None):
     mask_distance = float("inf") if args.mask_distance is None else args.mask_distance
     if mask_distance < 1:
         raise ValueError("mask distance must be an integer >= 1.")
-    sampler = ESM_MSA_sampler(models.ESM_MSA1(checkpoint=args.checkpoint, precision=args.precision), device=args.device)
+    sampler = ESM_MSA_sampler(models.ESM_MSA1(checkpoint=args.checkpoint, precision=args.precision, synthetic=args.synthetic_weights), device=args.device)
     input_handle = open(args.i) if args.i is not None else sys.stdin
     output_handle = open(args.o, "w") if args.o is not None else sys.stdout
     try:

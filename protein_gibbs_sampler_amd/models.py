@@ -2,56 +2,62 @@
 `.batch_converter` -- the plug-in contract of /root/reference/src/pgen/models.py:59-88.
 
 `.model` is a NativeMaskedLM (HIP engine handle) instead of a fair-esm nn.Module.  Weights: a real
-fair-esm checkpoint when one is given or found in torch's hub cache, otherwise seeded synthetic
-weights of the same architecture (a warning is printed: samples are then not biologically meaningful).
+fair-esm checkpoint when one is given or found in torch's hub cache.  Without one the constructor RAISES
+(as `esm.pretrained.*` fails in the reference when it cannot load) unless the caller opts in to seeded
+synthetic weights of the same architecture with `synthetic=True` (benchmarks, tests): samples from those
+are not biologically meaningful.
 """
-import warnings
 
 from . import weights as _w
 from .alphabet import Alphabet
 from .engine import NativeMaskedLM
 
 
-def _resolve_weights(cfg, state_dict, checkpoint, filename, seed):
+def _resolve_weights(cfg, state_dict, checkpoint, filename, seed, synthetic):
     if state_dict is not None:
         return state_dict
     path = checkpoint or _w.find_cached_checkpoint(filename)
     if path:
         return _w.load_fair_esm_checkpoint(path, cfg)
-    warnings.warn("no %s checkpoint available offline: using seeded synthetic weights (seed=%d)" % (filename, seed))
+    if not synthetic:
+        raise FileNotFoundError(
+            "no %s checkpoint: pass checkpoint=<path to the fair-esm .pt file> (CLI: --checkpoint) or place it in "
+            "~/.cache/torch/hub/checkpoints/.  Seeded synthetic weights of the same architecture are available only as an "
+            "explicit opt-in (synthetic=True / --synthetic-weights): output sampled from them is not biologically "
+            "meaningful." % filename)
     return _w.synthetic_state_dict(cfg, seed=seed)
 
 
 class _Wrapper:
-    def __init__(self, cfg, alphabet, msa, state_dict, checkpoint, filename, seed, precision):
+    def __init__(self, cfg, alphabet, msa, state_dict, checkpoint, filename, seed, precision, synthetic):
         self.cfg = cfg
         self.alphabet = alphabet
         self.batch_converter = alphabet.get_batch_converter(msa=msa)
-        self.model = NativeMaskedLM(cfg, _resolve_weights(cfg, state_dict, checkpoint, filename, seed), precision)
+        self.model = NativeMaskedLM(cfg, _resolve_weights(cfg, state_dict, checkpoint, filename, seed, synthetic), precision)
 
 
 class ESM1b(_Wrapper):
     """esm1b_t33_650M_UR50S (models.py:59-62)."""
 
-    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None):
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
         super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
-                         "esm1b_t33_650M_UR50S.pt", seed, precision)
+                         "esm1b_t33_650M_UR50S.pt", seed, precision, synthetic)
 
 
 class ESM1v(_Wrapper):
     """esm1v_t33_650M_UR90S (models.py:64-67): same architecture as ESM-1b, different weights."""
 
-    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None):
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
         super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
-                         "esm1v_t33_650M_UR90S_1.pt", seed, precision)
+                         "esm1v_t33_650M_UR90S_1.pt", seed, precision, synthetic)
 
 
 class ESM_MSA1(_Wrapper):
     """esm_msa1b_t12_100M_UR50S (models.py:84-88) with the reference's patched MSA batch converter."""
 
-    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None):
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
         super().__init__(config or dict(_w.MSA1B_CONFIG), Alphabet(True, False), True, state_dict, checkpoint,
-                         "esm_msa1b_t12_100M_UR50S.pt", seed, precision)
+                         "esm_msa1b_t12_100M_UR50S.pt", seed, precision, synthetic)
 
 
 def _esm1_unsupported(name):

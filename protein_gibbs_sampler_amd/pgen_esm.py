@@ -15,7 +15,7 @@ model_map = {"esm1b": models.ESM1b, "esm1v": models.ESM1v, "esm6": models.ESM6, 
 
 
 def main(input_h, output_p, args):
-    sampler = ESM_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision), device=args.device)
+    sampler = ESM_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision, synthetic=args.synthetic_weights), device=args.device)
     with open(output_p / "specification.tsv", "w") as output_h:
         for line in input_h:
             line = line.strip()

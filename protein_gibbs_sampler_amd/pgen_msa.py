@@ -17,7 +17,7 @@ model_map = {"esm_msa1": models.ESM_MSA1}
 
 def main(input_h, output_p, args):
     clean_flag = "delete" if args.delete_insertions else "upper"
-    sampler = ESM_MSA_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision), device=args.device)
+    sampler = ESM_MSA_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision, synthetic=args.synthetic_weights), device=args.device)
     with open(output_p / "specification.tsv", "w") as output_h:
         for line in input_h:
             line = line.strip()

@@ -99,7 +99,7 @@ def build_parser():
 def main(argv=None):
     args = build_parser().parse_args(argv)
     seed_everything(args.seed)
-    sampler = ESM_MSA_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision), device=args.device)
+    sampler = ESM_MSA_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision, synthetic=args.synthetic_weights), device=args.device)
     pgen_msa(args.templates, args.references, args.o, args.seqs_per_template, args.keep_identical, args.steps, args.passes,
              args.burn_in, args.device, args.model, args.alignment_size, args.ep, args.op, args.top_k, legacy=args.legacy,
              gap_percent_threshold=args.gap_percent_threshold, debug=args.debug, sampler=sampler)

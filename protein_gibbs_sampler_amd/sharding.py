@@ -5,9 +5,62 @@ Results are independent of the number of ranks because (a) every rank derives it
 table from the same CPython-exact stream (the whole table is generated natively on every rank: microseconds), and
 (b) token draws are keyed by the *global* chain id (`pg_sample_params.row_id_base`).
 """
+import random
+
 import numpy as np
 
 from . import pyrandom
+
+
+class DistContext:
+    """torch.distributed as the samplers see it: rank, world size and the module itself."""
+
+    def __init__(self, dist):
+        self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+
+
+def dist_context():
+    """A DistContext when this process is one of several torch.distributed ranks (RCCL or gloo), else None.
+    The samplers then split every batch of chains / MSAs contiguously over the ranks."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return None
+    return DistContext(dist)
+
+
+def broadcast_object(ctx, obj):
+    """rank 0's `obj` on every rank (host-side control data: seeds, RNG states)."""
+    box = [obj]
+    ctx.dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def sync_host_rng(ctx):
+    """Every rank continues from rank 0's interpreter RNG state, so all ranks derive the same position tables (each rank
+    generates the whole table natively and slices its block: no per-iteration communication)."""
+    random.setstate(broadcast_object(ctx, random.getstate()))
+
+
+def run_sharded(ctx, tokens, table, row_id_base, rows_per_item, run_fn, device=None):
+    """One batch over the ranks: item block [lo, hi) of `tokens` [B, ...] and `table` [iters, B, ...] goes through
+    run_fn(local_tokens, local_table, local_row_id_base) (in place), then ONE all-gather rebuilds the whole token buffer
+    on every rank.  rows_per_item = Philox row ids consumed per item (1 per chain, R per MSA)."""
+    import torch
+    B = tokens.shape[0]
+    lo, hi = shard_range(B, ctx.world, ctx.rank)
+    local = np.ascontiguousarray(tokens[lo:hi])
+    if hi > lo:
+        run_fn(local, np.ascontiguousarray(table[:, lo:hi]), row_id_base + lo * rows_per_item)
+    counts = [shard_range(B, ctx.world, r)[1] - shard_range(B, ctx.world, r)[0] for r in range(ctx.world)]
+    t = torch.from_numpy(local)
+    on_gpu = ctx.dist.get_backend() != "gloo"
+    if on_gpu:
+        t = t.to(device if device is not None else "cuda")
+    full = gather_tokens(ctx.dist, t, counts)
+    return full.cpu().numpy() if on_gpu else full.numpy()
 
 
 def shard_range(n_items, world_size, rank):

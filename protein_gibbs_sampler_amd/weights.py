@@ -87,37 +87,97 @@ def synthetic_state_dict(cfg, seed=0, std=0.02, embed_std=None, ln_jitter=0.0):
     return out
 
 
-_PREFIXES = ("encoder.sentence_encoder.", "sentence_encoder.", "encoder.", "model.")
+def _strip_fair_esm_prefixes(name):
+    """fair-esm's `_load_model_and_alphabet_core_v1` (esm/pretrained.py, [recalled]: the package is not installed here) drops
+    everything up to and including "encoder." and "sentence_encoder." from v1 checkpoint keys
+    (`encoder.sentence_encoder.layers.0...` -> `layers.0...`, `encoder.lm_head.dense.weight` -> `lm_head.dense.weight`)."""
+    for marker in ("sentence_encoder.", "encoder."):
+        if marker in name:
+            name = name.split(marker, 1)[1]
+    return name[len("model."):] if name.startswith("model.") else name
 
 
-def normalise_state_dict(sd, cfg):
-    """fair-esm checkpoint keys -> the engine's keys (strip fair-esm's wrapper prefixes, untie lm_head)."""
+def _swap_row_column(name):
+    """MSA Transformer checkpoints only: fair-esm's loader exchanges "row" and "column" in every key (its lambda `prs3`):
+    in esm_msa1b_t12_100M_UR50S.pt the tensors stored as `row_self_attention.*` belong to the module's
+    `column_self_attention` and vice versa.  All of them are d x d, so loading them unswapped would not fail -- it would
+    silently put the tied-row weights into column attention."""
+    if "row" in name:
+        return name.replace("row", "column")
+    return name.replace("column", "row")
+
+
+def normalise_state_dict(sd, cfg, fair_esm_layout=True):
+    """fair-esm checkpoint keys -> the engine's keys.
+
+    fair_esm_layout=True applies what fair-esm's own loader does to an on-disk checkpoint: prefix stripping, and for the
+    MSA Transformer the row<->column swap.  Pass False for a state dict that already has module names (e.g. one taken
+    from a constructed fair-esm model with `model.state_dict()`, or `synthetic_state_dict`).
+    Shapes are checked exactly; a tied decoder (`lm_head.weight`) must equal `embed_tokens.weight`."""
     want = tensor_shapes(cfg)
-    out = {}
+    is_msa = cfg["arch"] == _lib.PG_ARCH_MSA1B
+    named = {}
     for k, v in sd.items():
         name = k
-        changed = True
-        while changed:
-            changed = False
-            for p in _PREFIXES:
-                if name.startswith(p):
-                    name = name[len(p):]
-                    changed = True
-        name = re.sub(r"^lm_head\.weight$", "embed_tokens.weight", name) if "embed_tokens.weight" not in sd else name
-        if name in want:
-            arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
-            out[name] = np.ascontiguousarray(arr.reshape(want[name]), dtype=np.float32)
+        if fair_esm_layout:
+            name = _strip_fair_esm_prefixes(name)
+            if is_msa:
+                name = _swap_row_column(name)
+        arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
+        named[name] = arr
+    if "lm_head.weight" in named:
+        if "embed_tokens.weight" not in named:
+            named["embed_tokens.weight"] = named["lm_head.weight"]
+        elif not np.array_equal(named["lm_head.weight"], named["embed_tokens.weight"]):
+            raise ValueError("checkpoint has an untied lm_head.weight: this engine implements the tied decoder of ESM-1b / MSA-1b")
+    out = {}
+    for name, shape in want.items():
+        if name not in named:
+            continue
+        arr = named[name]
+        if tuple(arr.shape) != tuple(shape):
+            raise ValueError("tensor %r has shape %s, expected %s" % (name, tuple(arr.shape), tuple(shape)))
+        out[name] = np.ascontiguousarray(arr, dtype=np.float32)
     missing = [k for k in want if k not in out]
     if missing:
         raise KeyError("checkpoint is missing %d tensors, e.g. %s" % (len(missing), missing[:3]))
+    if fair_esm_layout and cfg.get("token_dropout"):
+        # fair-esm zeroes the <mask> embedding row when it loads an ESM-1b checkpoint ("For token drop", [recalled]); the
+        # forward never reads that row as an input (masked positions are zeroed), but the tied decoder does: logit[<mask>]
+        out["embed_tokens.weight"] = out["embed_tokens.weight"].copy()
+        out["embed_tokens.weight"][cfg["mask_idx"]] = 0.0
     return out
 
 
 def load_fair_esm_checkpoint(path, cfg):
+    """Read a fair-esm `.pt` file ({"args"/"cfg": ..., "model": state dict}) as the reference does through
+    `esm.pretrained.*` (/root/reference/src/pgen/models.py:61,86)."""
     import torch
     blob = torch.load(path, map_location="cpu", weights_only=False)
     sd = blob["model"] if isinstance(blob, dict) and "model" in blob else blob
-    return normalise_state_dict(sd, cfg)
+    arch = None
+    if isinstance(blob, dict):
+        a = blob.get("args")
+        arch = a.get("arch") if isinstance(a, dict) else getattr(a, "arch", None)
+        if arch is None and isinstance(blob.get("cfg"), dict):
+            arch = blob["cfg"].get("model", {}).get("arch") if isinstance(blob["cfg"].get("model"), dict) else None
+    want_msa = cfg["arch"] == _lib.PG_ARCH_MSA1B
+    if arch is not None and (arch == "msa_transformer") != want_msa:
+        raise ValueError("checkpoint arch %r does not match the requested %s engine" % (arch, "MSA-1b" if want_msa else "ESM-1b"))
+    return normalise_state_dict(sd, cfg, fair_esm_layout=True)
+
+
+def to_fair_esm_checkpoint_layout(sd, cfg):
+    """Inverse of the key mapping above: engine/module names -> the on-disk fair-esm v1 key layout (used to write test
+    fixtures and to export weights): `encoder.sentence_encoder.` prefix on trunk tensors, `encoder.` on the LM head, and
+    row<->column exchanged for the MSA Transformer."""
+    is_msa = cfg["arch"] == _lib.PG_ARCH_MSA1B
+    out = {}
+    for name, v in sd.items():
+        k = _swap_row_column(name) if is_msa else name
+        k = ("encoder." + k) if k.startswith("lm_head.") else ("encoder.sentence_encoder." + k)
+        out[k] = v
+    return out
 
 
 def find_cached_checkpoint(filename):

@@ -93,7 +93,8 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
     out = tmp_path / "out"
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        pgen_esm.cli(["-i", str(spec), "-o", str(out), "--num_output_sequences", "5", "--batch_size", "2", "--seed", "3"])
+        pgen_esm.cli(["-i", str(spec), "-o", str(out), "--num_output_sequences", "5", "--batch_size", "2", "--seed", "3",
+                      "--synthetic-weights"])
     assert (out / "specification.tsv").read_text().count("\n") == 2
     names, seqs = fasta_io.parse_fasta(out / "first.fasta", return_names=True)
     assert names == [str(i) for i in range(5)] and all(len(s) == 25 and set(s) <= set("ACDEFGHIKLMNPQRSTVWY") for s in seqs)
@@ -105,6 +106,9 @@ def test_cli_end_to_end(tmp_path, monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         pgen_msa.cli(["-i", str(spec2), "-o", str(out), "--num_output_sequences", "6", "--alignment_size", "3",
-                      "--keep_first_sequence", "--delete_insertions", "--seed", "1"])
+                      "--keep_first_sequence", "--delete_insertions", "--seed", "1", "--synthetic-weights"])
     seqs = fasta_io.parse_fasta(out / "m1.fasta")
     assert len(seqs) == 6 and all(len(s) == 10 and set(s) <= set("-ACDEFGHIKLMNPQRSTVWY") for s in seqs)
+    # without a checkpoint and without the explicit opt-in the front end must fail, not sample from random weights
+    with pytest.raises(FileNotFoundError, match="synthetic"):
+        pgen_esm.cli(["-i", str(spec), "-o", str(out), "--num_output_sequences", "1"])

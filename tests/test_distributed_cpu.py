@@ -83,3 +83,86 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---- the product entry point: ESM_sampler.generate / ESM_MSA_sampler.generate over torch.distributed ranks --------------
+def _fake_engine_model(msa):
+    """A plug-in whose `.model` is a NativeMaskedLM subclass with the device call replaced by a deterministic function of
+    (global Philox row id, iteration, slot): what the sharded generate() must reproduce for any number of ranks."""
+    from protein_gibbs_sampler_amd.alphabet import Alphabet
+    from protein_gibbs_sampler_amd.engine import NativeMaskedLM
+
+    class FakeLM(NativeMaskedLM):
+        def __init__(self):
+            self.calls = []
+
+        def eval(self):
+            return self
+
+        def to(self, device):
+            return self
+
+        def gibbs_run(self, tokens, target_idx, params, want_logits=False, want_tokens=False):
+            self.calls.append(tokens.shape)
+            flat = tokens.reshape(-1, tokens.shape[-1])
+            idx = np.asarray(target_idx).reshape(target_idx.shape[0], -1, target_idx.shape[-1])
+            for it in range(idx.shape[0]):
+                for r in range(flat.shape[0]):
+                    for p in range(idx.shape[2]):
+                        flat[r, idx[it, r, p]] = 4 + ((params.row_id_base + r) * 7 + it * 3 + p + params.rng_seed) % 20
+            return None, None
+
+    class Plug:
+        pass
+
+    plug = Plug()
+    plug.alphabet = Alphabet(True, not msa)
+    plug.batch_converter = plug.alphabet.get_batch_converter(msa=msa)
+    plug.model = FakeLM()
+    return plug
+
+
+def _generate_both(seed):
+    """ESM: 2 batches of 5 chains (ragged split 3 + 2 over two ranks); MSA: 2 rounds of 3 MSAs x 2 rows."""
+    import torch as _t
+    _t.cuda.is_available = lambda: True
+    _t.cuda.device_count = lambda: 1
+    from protein_gibbs_sampler_amd import esm_msa_sampler, esm_sampler
+    s = esm_sampler.ESM_sampler(_fake_engine_model(False), device="gpu")
+    s.draw_seed = 11
+    random.seed(seed)
+    a = s.generate(9, ["MEPAATGQEAEECAHSGRGEAW", "MKPAATGQEA"], batch_size=5, num_iters=3, num_positions=4, show_progress_bar=False)
+    m = esm_msa_sampler.ESM_MSA_sampler(_fake_engine_model(True), device="gpu")
+    m.draw_seed = 12
+    b = m.generate(11, ["MEPAATGQ", "MEP-ATGQ"], batch_size=3, num_iters=2, num_positions=3, show_progress_bar=False)
+    return a, b, random.getrandbits(32), s.model.model.calls, m.model.model.calls
+
+
+def _gen_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = _generate_both(seed=1 if rank == 0 else 999)        # rank 1's own seed must not matter: rank 0's RNG state is broadcast
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_generate_shards_batches_over_two_ranks():
+    want_a, want_b, want_state, calls_a, calls_b = _generate_both(seed=1)
+    assert calls_a == [(5, 24)] * 2 and calls_b == [(3, 2, 9)] * 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gen_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        a, b, state, ca, cb = got[rank]
+        assert a == want_a and b == want_b                    # every rank returns the full, identical result
+        assert state == want_state                            # and leaves the interpreter RNG where one process would
+    assert got[0][3] == [(3, 24)] * 2 and got[1][3] == [(2, 24)] * 2          # contiguous blocks: 3 + 2 chains
+    assert got[0][4] == [(2, 2, 9)] * 2 and got[1][4] == [(1, 2, 9)] * 2      # 2 + 1 MSAs

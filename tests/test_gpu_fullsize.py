@@ -88,10 +88,47 @@ def test_config2_full_size_rows_are_independent(sampler):
     assert (lm.forward_logits(tok[:128]) == full[:128]).all()
     assert (lm.forward_logits(tok[128:]) == full[128:]).all()         # includes the rows of the full batch's peeled panels
     assert (lm.forward_logits(tok[100:200]) == full[100:200]).all()
+    # BASELINE config 3 gives each of 8 GPUs a 32-chain shard (8256 token rows): same logits, bit for bit, and 64 / 128 for
+    # the 4- and 2-GPU points of the scaling curve
+    for g in (0, 3, 7):
+        assert (lm.forward_logits(tok[g * 32:(g + 1) * 32]) == full[g * 32:(g + 1) * 32]).all()
+    assert (lm.forward_logits(tok[64:128]) == full[64:128]).all()
     few = lm.forward_logits(tok[-3:])
     d = np.abs(few - full[-3:]).max()
     print("\nfull-size: 3 chains alone vs in the batch: max|diff| = %.3e (logit std %.2f)" % (d, full.std()))
     assert d < 0.05
+
+
+def test_config3_shards_reproduce_the_single_gpu_gibbs_run(sampler):
+    """The whole Gibbs job of config 2, re-run as the eight 32-chain shards config 3 puts on eight GPUs (here one after the
+    other on one GPU, each with its slice of the one position stream and its global chain ids): final tokens identical."""
+    import ctypes
+    import torch
+    from protein_gibbs_sampler_amd import _lib, pyrandom, sharding
+    B, L, P, iters = 256, 256, 25, 3
+    T = L + 2
+    rng = np.random.default_rng(1234)
+    tok_all = np.concatenate([np.zeros((B, 1), np.int64), rng.integers(4, 24, (B, L)), np.full((B, 1), 2)], axis=1).astype(np.int32)
+    lm = sampler.model.model
+    L_ = _lib.lib()
+
+    def run(lo, hi):
+        r = pyrandom.NativePyRandom()
+        r.seed(0)
+        table = sharding.local_slice(sharding.global_position_table(r, list(range(1, L + 1)), P, iters, B), lo, hi)
+        params = _lib.make_sample_params(True, 32, 0, float("inf"), 1.0, sampler.valid_aa_idx, rng_seed=0, row_id_base=lo)
+        d_tok = torch.from_numpy(tok_all[lo:hi].copy()).cuda()
+        d_idx = torch.from_numpy(table).cuda()
+        _lib.check(L_.pg_esm_gibbs_run_device(lm.handle, ctypes.c_void_p(d_tok.data_ptr()), hi - lo, T,
+                                              ctypes.c_void_p(d_idx.data_ptr()), iters, P, ctypes.byref(params), None, None))
+        lm.synchronize()
+        return d_tok.cpu().numpy()
+
+    whole = run(0, B)
+    assert (whole != tok_all).any()
+    for world in (8, 2):
+        parts = [run(*sharding.shard_range(B, world, g)) for g in range(world)]
+        assert (np.concatenate(parts) == whole).all(), "world=%d" % world
 
 
 def test_config4_full_size_msa_gibbs_properties():

@@ -1,0 +1,87 @@
+"""ALL emitted logits at the REAL model sizes against the fp32 CPU oracle, in both precision modes.
+
+The call these tests stand for is `self.model.model(batch)["logits"]` (/root/reference/src/pgen/esm_sampler.py:223,
+esm_msa_sampler.py:136,236).  north_star's tolerance is 1e-3 on emitted logits: the strict mode (PG_PREC_FP32:
+split-bf16 x3 MFMA GEMMs + fp32 attention) is held to it here at 33 layers x d=1280 (ESM-1b) and 12 layers x d=768
+(ESM-MSA-1b); the bf16 throughput mode is measured, printed and bounded (it does NOT meet 1e-3).
+Weights are synthetic but scaled so the logits have a realistic spread (std 4-8; real ESM-1b logits span about -15..15).
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle.esm_forward import EsmConfig, esm1b_forward
+from oracle.msa_forward import MsaConfig, msa_forward
+from protein_gibbs_sampler_amd import models, weights
+
+pytestmark = pytest.mark.gpu
+
+STRICT_TOL = 1e-3      # north_star
+BF16_BOUND = 0.25      # bf16 operands through 33 layers at logit std ~6: measured 0.05-0.15, printed below
+
+
+@pytest.fixture(scope="module")
+def esm_case():
+    cfg = dict(weights.ESM1B_CONFIG)
+    sd = weights.synthetic_state_dict(cfg, seed=11, std=0.025, embed_std=0.3, ln_jitter=0.1)
+    rng = np.random.default_rng(21)
+    B, L = 3, 256                                                        # config 2's chain shape (T = 258)
+    tok = np.concatenate([np.zeros((B, 1), np.int64), rng.integers(4, 24, (B, L)), np.full((B, 1), 2)], axis=1)
+    for b in range(B):
+        tok[b, rng.choice(np.arange(1, L + 1), 25, replace=False)] = 32   # 10 % masked, as in a Gibbs iteration
+    want = esm1b_forward(sd, EsmConfig(), tok)
+    return cfg, sd, tok, want
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_esm1b_full_size_all_logits(esm_case, precision):
+    cfg, sd, tok, want = esm_case
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = models.ESM1b(state_dict=sd, config=cfg, precision=precision).model.to("cuda:0")
+    got = m.forward_logits(tok)
+    assert got.shape == want.shape == (3, 258, 33)
+    err = np.abs(got - want)
+    agree = (got.argmax(-1) == want.argmax(-1)).mean()
+    print("\n[ESM-1b 33 x 1280, %s] max|engine - oracle| = %.3e  mean = %.3e  (logit std %.2f, max|logit| %.1f, argmax agreement %.4f)"
+          % (precision, err.max(), err.mean(), want.std(), np.abs(want).max(), agree))
+    if precision == "fp32":
+        assert err.max() < STRICT_TOL
+        assert agree > 0.999            # flips only between near-tied logits (gap < 2e-3)
+    else:
+        assert err.max() < BF16_BOUND and agree > 0.97
+
+
+@pytest.fixture(scope="module")
+def msa_case():
+    cfg = dict(weights.MSA1B_CONFIG)
+    sd = weights.synthetic_state_dict(cfg, seed=12, std=0.025, embed_std=0.3, ln_jitter=0.1)
+    rng = np.random.default_rng(22)
+    B, R, C = 1, 32, 257                                                 # one MSA of config 4
+    tok = rng.integers(4, 24, (B, R, C))
+    tok[rng.random((B, R, C)) < 0.1] = 30                                # gaps
+    for r in range(R):
+        tok[0, r, rng.choice(np.arange(1, C), 25, replace=False)] = 32
+    tok[..., 0] = 0
+    want = msa_forward(sd, MsaConfig(), tok)
+    return cfg, sd, tok, want
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_msa1b_full_size_all_logits(msa_case, precision):
+    cfg, sd, tok, want = msa_case
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = models.ESM_MSA1(state_dict=sd, config=cfg, precision=precision).model.to("cuda:0")
+    got = m.forward_logits(tok)
+    assert got.shape == want.shape == (1, 32, 257, 33)
+    err = np.abs(got - want)
+    agree = (got.argmax(-1) == want.argmax(-1)).mean()
+    print("\n[MSA-1b 12 x 768, %s] max|engine - oracle| = %.3e  mean = %.3e  (logit std %.2f, max|logit| %.1f, argmax agreement %.4f)"
+          % (precision, err.max(), err.mean(), want.std(), np.abs(want).max(), agree))
+    if precision == "fp32":
+        assert err.max() < STRICT_TOL
+        assert agree > 0.999            # flips only between near-tied logits (gap < 2e-3)
+    else:
+        assert err.max() < BF16_BOUND and agree > 0.97

@@ -20,7 +20,7 @@ def esm():
     cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=1, d_ffn=256, max_positions=64)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return esm_sampler.ESM_sampler(models.ESM1b(config=cfg), device="cpu")
+        return esm_sampler.ESM_sampler(models.ESM1b(config=cfg, synthetic=True), device="cpu")
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +28,7 @@ def msa():
     cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=128, n_layers=1, d_ffn=256, max_positions=64, max_msa_rows=16)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return esm_msa_sampler.ESM_MSA_sampler(models.ESM_MSA1(config=cfg), device="cpu")
+        return esm_msa_sampler.ESM_MSA_sampler(models.ESM_MSA1(config=cfg, synthetic=True), device="cpu")
 
 
 # ---- device grammar (reference esm_sampler.py:66-78; test_esm_sampler.py:39-40) -------------------
@@ -36,7 +36,7 @@ def test_sampler_init_gpu_when_not_available(mock_no_gpu):
     cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=1, d_ffn=256, max_positions=64)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        m = models.ESM1b(config=cfg)
+        m = models.ESM1b(config=cfg, synthetic=True)
     with pytest.raises(Exception) as e:
         esm_sampler.ESM_sampler(m, device="gpu")
     assert str(e.value) == "gpu requested, but No Cuda devices found"
@@ -179,27 +179,81 @@ def test_duplicate_indexes_are_shadowed():
     assert t[0, 0].tolist() == [3 | _gibbs.SHADOW_BIT, 5, 3, 7]
 
 
+def _write_fair_esm_pt(path, sd, cfg, arch, tied_only=True, extra=True):
+    """A `.pt` as fair-esm stores it: {"args": Namespace(arch=...), "model": {on-disk keys}} -- trunk tensors under
+    `encoder.sentence_encoder.`, the LM head under `encoder.`, row/column exchanged for the MSA Transformer, the tied
+    decoder stored as `encoder.lm_head.weight`, plus tensors this engine does not use (contact head)."""
+    import argparse
+    import torch
+    from protein_gibbs_sampler_amd import weights
+    disk = {k: torch.from_numpy(v).double() for k, v in weights.to_fair_esm_checkpoint_layout(sd, cfg).items()}
+    disk["encoder.lm_head.weight"] = disk["encoder.sentence_encoder.embed_tokens.weight"].clone()
+    if tied_only:
+        del disk["encoder.sentence_encoder.embed_tokens.weight"]
+    if extra:
+        disk["encoder.sentence_encoder.contact_head.regression.weight"] = torch.zeros(1, 40)
+    torch.save({"model": disk, "args": argparse.Namespace(arch=arch)}, path)
+    return disk
+
+
 def test_fair_esm_checkpoint_layout_round_trip(tmp_path):
-    """A `.pt` in fair-esm's layout ({"model": {"encoder.sentence_encoder.<key>": tensor, ...}, "args": ...}, tied decoder
-    stored as `lm_head.weight`, extra buffers such as `contact_head.*`) loads into the engine's key set."""
+    """ESM-1b layout: prefixes stripped, tied decoder recovered, extra tensors ignored, dtypes -> fp32, shapes
+    checked exactly, and -- as fair-esm does when it loads an ESM-1b checkpoint -- the <mask> embedding row zeroed."""
     import torch
     from protein_gibbs_sampler_amd import weights
     cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=64, n_layers=2, d_ffn=128, max_positions=20)
     sd = weights.synthetic_state_dict(cfg, seed=3)
-    blob = {"model": {}, "args": {"arch": "roberta_large"}}
-    for k, v in sd.items():
-        if k == "embed_tokens.weight":
-            blob["model"]["encoder.lm_head.weight"] = torch.from_numpy(v).clone()     # only the tied copy is present
-            continue
-        blob["model"]["encoder.sentence_encoder." + k if not k.startswith("lm_head") else "encoder." + k] = torch.from_numpy(v).double()
-    blob["model"]["encoder.sentence_encoder.contact_head.regression.weight"] = torch.zeros(1, 40)
     path = tmp_path / "esm_tiny.pt"
-    torch.save(blob, path)
+    disk = _write_fair_esm_pt(path, sd, cfg, "roberta_large")
     got = weights.load_fair_esm_checkpoint(str(path), cfg)
     assert set(got) == set(sd)
     for k in sd:
-        assert got[k].dtype == np.float32 and got[k].shape == sd[k].shape and (got[k] == sd[k]).all(), k
+        want = sd[k].copy()
+        if k == "embed_tokens.weight":
+            want[cfg["mask_idx"]] = 0
+        assert got[k].dtype == np.float32 and got[k].shape == sd[k].shape and (got[k] == want).all(), k
+    # both copies of the tied matrix present and equal: fine; different: refused
+    _write_fair_esm_pt(path, sd, cfg, "roberta_large", tied_only=False)
+    assert set(weights.load_fair_esm_checkpoint(str(path), cfg)) == set(sd)
+    blob = torch.load(path, weights_only=False)
+    blob["model"]["encoder.lm_head.weight"][3, 3] += 1
+    torch.save(blob, path)
+    with pytest.raises(ValueError, match="untied"):
+        weights.load_fair_esm_checkpoint(str(path), cfg)
+    # a transposed tensor with the right element count must not load silently
+    blob = {"model": dict(disk), "args": {"arch": "roberta_large"}}
+    blob["model"]["encoder.sentence_encoder.layers.0.fc1.weight"] = disk["encoder.sentence_encoder.layers.0.fc1.weight"].T.contiguous()
+    torch.save(blob, path)
+    with pytest.raises(ValueError, match="layers.0.fc1.weight.*shape"):
+        weights.load_fair_esm_checkpoint(str(path), cfg)
+    blob["model"] = dict(disk)
     del blob["model"]["encoder.sentence_encoder.layers.1.fc2.bias"]
     torch.save(blob, path)
     with pytest.raises(KeyError, match="missing 1 tensors"):
         weights.load_fair_esm_checkpoint(str(path), cfg)
+    # an MSA checkpoint handed to the ESM-1b engine is refused by its declared arch
+    _write_fair_esm_pt(path, sd, cfg, "msa_transformer")
+    with pytest.raises(ValueError, match="arch"):
+        weights.load_fair_esm_checkpoint(str(path), cfg)
+
+
+def test_fair_esm_msa_checkpoint_swaps_row_and_column(tmp_path):
+    """esm_msa1b_t12_100M_UR50S.pt stores the two axial-attention blocks under exchanged names; fair-esm's loader swaps
+    "row" <-> "column" in every key.  The tensors are all d x d, so only a value check can see a missed swap."""
+    from protein_gibbs_sampler_amd import weights
+    cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=64, n_layers=2, d_ffn=128, max_positions=20, max_msa_rows=8)
+    sd = weights.synthetic_state_dict(cfg, seed=5)
+    path = tmp_path / "msa_tiny.pt"
+    disk = _write_fair_esm_pt(path, sd, cfg, "msa_transformer")
+    # on disk the module's row attention sits under "column_self_attention" (and vice versa)
+    k_row = "layers.0.row_self_attention.layer.q_proj.weight"
+    assert (disk["encoder.sentence_encoder.layers.0.column_self_attention.layer.q_proj.weight"].float().numpy() == sd[k_row]).all()
+    assert "encoder.sentence_encoder.msa_position_embedding" in disk
+    got = weights.load_fair_esm_checkpoint(str(path), cfg)
+    assert set(got) == set(sd)
+    for k in sd:
+        assert (got[k] == sd[k]).all(), k                      # MSA-1b has no token dropout: nothing is zeroed
+    assert not (got[k_row] == sd["layers.0.column_self_attention.layer.q_proj.weight"]).all()
+    # module-named state dicts (already swapped by fair-esm) go through with fair_esm_layout=False
+    again = weights.normalise_state_dict(sd, cfg, fair_esm_layout=False)
+    assert all((again[k] == sd[k]).all() for k in sd)

@@ -80,3 +80,26 @@ def test_embedding_matches_esm_oracle_pieces():
         + W["msa_position_embedding"].reshape(-1, 128)[:3][None, :, None, :]
     want = E.layer_norm(raw, W["emb_layer_norm_before.weight"], W["emb_layer_norm_before.bias"])
     assert np.abs(x - want).max() < 1e-5
+
+
+# ---- second pin: fair-esm's own tensor layout and its chunked (max_tokens_per_msa) paths -----------------------------------
+def test_oracle_equals_fair_esm_layout_restatement_and_chunked_paths():
+    """"chunked == unchunked".  tests/_msa_alt.py restates the forward in fair-esm's R x C x B x D layout
+    with its einsum strings (torch); it must agree with oracle/msa_forward.py (B x R x C x D, numpy), and its memory-bounded
+    row-chunk / column-chunk paths must agree with the one-shot path."""
+    from _msa_alt import msa_forward_alt
+    ck = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=80, max_rows=16)
+    ocfg = MsaConfig(**ck)
+    sd = synthetic_msa_weights(ocfg, seed=21, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    rng = np.random.default_rng(4)
+    for (B, R, C) in [(2, 5, 23), (1, 1, 9), (1, 12, 40)]:
+        tok = rng.integers(4, 24, (B, R, C))
+        tok[rng.random((B, R, C)) < 0.1] = 30
+        tok[rng.random((B, R, C)) < 0.1] = 32
+        tok[..., 0] = 0
+        want = msa_forward(sd, ocfg, tok)
+        alt = msa_forward_alt(sd, 2, 2, tok)
+        assert np.abs(alt - want).max() < 5e-5 * max(1.0, np.abs(want).max())
+        for max_tokens in (C * 2, C + 3, 7):                    # 2 rows per chunk / 1 row + ragged columns / tiny
+            chunked = msa_forward_alt(sd, 2, 2, tok, max_tokens_per_msa=max_tokens)
+            assert np.abs(chunked - alt).max() < 2e-5 * max(1.0, np.abs(alt).max())
