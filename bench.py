@@ -146,6 +146,7 @@ def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, target_se
            "sample": "%d of %d chains x 1 Gibbs iteration (L=%d, P=%d), fp32 numpy/OpenBLAS oracle, %.1f s" % (b, B, L, P, t)}
 
     # the oracle as checker: logits of both engine modes at the sampled rows of those b chains
+    cfg2_logits = keep["logits"]
     check = {"chains": b, "rows": int(b * P), "logit_std": float(keep["logits"].std())}
     for name, eng in (("bf16", lm), ("fp32", lm_strict)):
         if eng is None:
@@ -167,7 +168,7 @@ def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, target_se
 
     # reference-style sampling loop: the reference draws position by position in Python (esm_sampler.py:225-234); the
     # oracle's scalar generate_step stands in for it (one call per sampled position, one core)
-    rows = keep["logits"]
+    rows = cfg2_logits
     n = min(len(rows), 400)
     t0 = time.perf_counter()
     for i in range(n):

@@ -14,7 +14,7 @@ from oracle.msa_forward import MsaConfig, msa_forward
 from protein_gibbs_sampler_amd import _lib, esm_msa_sampler, esm_sampler, models, weights
 
 pytestmark = pytest.mark.gpu
-BF16_TOL = 0.15
+BF16_REL = 0.03      # bf16 throughput mode: max logit error held to 3 % of the logit spread (std); strict mode: 1e-3 absolute
 
 
 def _write_pt(path, sd, cfg, arch):
@@ -24,7 +24,7 @@ def _write_pt(path, sd, cfg, arch):
     torch.save({"model": disk, "args": argparse.Namespace(arch=arch)}, path)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16", BF16_TOL), ("fp32", 1e-3)])
+@pytest.mark.parametrize("precision,tol", [("bf16", None), ("fp32", 1e-3)])
 def test_esm1b_checkpoint_file_drives_the_engine(tmp_path, precision, tol):
     cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=3, d_ffn=256, max_positions=64)
     sd = weights.synthetic_state_dict(cfg, seed=8, std=0.08, embed_std=0.5, ln_jitter=0.1)
@@ -41,11 +41,11 @@ def test_esm1b_checkpoint_file_drives_the_engine(tmp_path, precision, tol):
     want = esm1b_forward(ref_sd, EsmConfig(d_model=128, n_layers=3, n_heads=2, d_ffn=256, max_pos=64), tok)
     err = np.abs(got - want).max()
     print("\ncheckpoint -> engine (ESM-1b layout, %s): max|engine - oracle| = %.3e (logit std %.2f)" % (precision, err, want.std()))
-    assert err < tol
+    assert err < (tol if tol else BF16_REL * want.std())
     assert np.abs(got[..., 32] - sd["lm_head.bias"][32]).max() < 1e-6       # logit[<mask>] = bias only (zeroed tied row)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16", BF16_TOL), ("fp32", 1e-3)])
+@pytest.mark.parametrize("precision,tol", [("bf16", None), ("fp32", 1e-3)])
 def test_msa1b_checkpoint_file_drives_the_engine(tmp_path, precision, tol):
     """The MSA layout has row/column exchanged on disk: loading it unswapped gives different logits (checked too)."""
     cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=128, n_layers=2, d_ffn=256, max_positions=64, max_msa_rows=8)
@@ -60,10 +60,12 @@ def test_msa1b_checkpoint_file_drives_the_engine(tmp_path, precision, tol):
     ocfg = MsaConfig(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=64, max_rows=8)
     want = msa_forward(sd, ocfg, tok)
     err = np.abs(got - want).max()
-    print("\ncheckpoint -> engine (MSA layout, %s): max|engine - oracle| = %.3e (logit std %.2f)" % (precision, err, want.std()))
-    assert err < tol
     unswapped = {weights._swap_row_column(k): v for k, v in sd.items()}
-    assert np.abs(msa_forward(unswapped, ocfg, tok) - want).max() > 10 * max(err, 1e-3)   # the swap is not a no-op on these weights
+    swap_effect = np.abs(msa_forward(unswapped, ocfg, tok) - want).max()
+    print("\ncheckpoint -> engine (MSA layout, %s): max|engine - oracle| = %.3e (logit std %.2f; a missed row/column swap would "
+          "move logits by %.2f)" % (precision, err, want.std(), swap_effect))
+    assert err < (tol if tol else BF16_REL * want.std())
+    assert swap_effect > 0.5 and err < swap_effect / 3           # the swap is not a no-op on these weights, and it was applied
 
 
 def test_models_refuse_to_run_without_checkpoint():
