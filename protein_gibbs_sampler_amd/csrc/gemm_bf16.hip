@@ -359,7 +359,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
 template <int EPI, int ABL = 0, int GM = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int stagger) {
+                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
 
@@ -369,12 +369,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   const int wm = grp, wn = wave & 3;              // wave tile: rows wm*128.. of X, rows wn*64.. of W
 
   int bid = blockIdx.x;
-  // XCD stagger: the epilogue is a chip-wide HBM burst when all 256 CUs finish their tiles together (one XCD storing alone
-  // is ~6x faster per tile, tools/xcd_epi_test.py).  The first workgroup on every CU of XCD x starts x * stagger * 0.25 us
-  // late; all tiles take the same time, so the XCDs keep that phase offset for the whole launch.
-  if (stagger && bid < 256) {
-    for (int i = (bid & 7) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(8);
-  }
   if (ABL == 18 && (bid & 7) != 0) return;        // timing experiment: only the workgroups of XCD 0 run (1/8 of the tiles)
   if (ABL == 19 && (bid & 7) > 1) return;         // ... XCDs 0 and 1
   {
@@ -527,30 +521,28 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   if (!abl && use_w4 && K >= 128) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles), block(512);
-  static const int stagger_env = [] { const char* e = getenv("PGIBBS_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-  const int stagger = n_tiles >= 512 ? stagger_env : 0;
   if (abl) {   // ablations: EPI_BF16 only
-    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 13) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 14) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 18) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 18>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 19) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 19>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 28) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 18>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 29) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 17) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 17>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 16) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 15) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 15>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
-    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger);
+    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 13) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 14) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 18) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 18>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 19) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 19>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 28) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 18>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 29) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 17) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 17>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 16) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 15) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 15>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
     PG_HIP(hipGetLastError());
     return 0;
   }
@@ -560,9 +552,9 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   const int gm = gm_env ? gm_env : (K >= 4096 ? 2 : 4);
 #define PG_GEMM_CASE(E)                                                                                                   \
   case E:                                                                                                                 \
-    if (gm == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
-    else if (gm == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
-    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, stagger); \
+    if (gm == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
+    else if (gm == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
+    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
