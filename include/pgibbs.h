@@ -74,7 +74,8 @@ typedef struct pg_engine pg_engine;
 #define PG_ARCH_MSA1B 2 /* fair-esm MSATransformer (esm_msa1b_t12_100M_UR50S) */
 
 #define PG_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream (throughput mode) */
-#define PG_PREC_FP32 1 /* fp32 MFMA operands and accumulate (parity mode, 1/16 of the bf16 MFMA rate) */
+#define PG_PREC_FP32 1 /* strict parity mode: every GEMM as three bf16 MFMA GEMMs on (hi, lo) splits of both operands (hi.hi +
+                          hi.lo + lo.hi, fp32 accumulate), fp32 attention; ~5x slower, logits within 1e-3 of the fp32 oracle */
 
 typedef struct {
   int32_t arch;
@@ -128,7 +129,7 @@ typedef struct {
  *   (esm_sampler.py:209-234) for one batch: per iteration mask scatter -> forward -> restrict /
  *   temperature / top-k / categorical -> write-back, all on the device with no host round trip.
  *   target_idx[n_iters][B][P] are the (1-based token) positions chosen on the host; entries < 0 are
- *   skipped (ragged lists); bit 30 set = position already written by a later duplicate in the same
+ *   skipped (ragged lists); positions >= T are PG_ERR_INVALID (the *_device variants skip them); bit 30 set = position already written by a later duplicate in the same
  *   row (sampled but not written back: keeps the reference's sequential last-write-wins result).
  *   Optional outputs (NULL to skip): sampled_logits[n_iters][B][P][V], sampled_tokens[n_iters][B][P].
  */

@@ -817,7 +817,7 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
     const long full = t256 / n_cu, frac = t256 - full * n_cu;
     const int m_main = (int)(full * n_cu / tiles_n);
     const int peel_rows = (tiles_m - m_main) * 256;
-    if (peel_on && frac > 0 && 2 * frac <= n_cu && full >= 2 && m_main > 0 && peel_rows <= 4096) {
+    if (peel_on && frac > 0 && 2 * frac <= n_cu && full >= 1 && m_main > 0 && peel_rows <= 4096) {
       int rc = launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi);
       if (rc) return rc;
       const size_t esz = (epi == EPI_BF16 || epi == EPI_BF16_GELU) ? 2 : 4;

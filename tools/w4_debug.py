@@ -33,8 +33,11 @@ for (M, N, K, epi) in CASES:
     err = np.abs(out - ref)
     bad = err > (0.03 if epi >= 3 else 2e-3) * max(1.0, np.abs(ref).max())
     print("M=%d N=%d K=%d epi=%d: max err %.3e, bad %d of %d" % (M, N, K, epi, err.max(), bad.sum(), bad.size))
+    FAIL = globals().get("FAIL", 0) + int(bad.any())
     if bad.any():
         mm, nn = np.nonzero(bad)
         print("   bad m%%256: %s" % np.unique(mm % 256)[:40])
         print("   bad n%%256: %s" % np.unique(nn % 256)[:40])
         print("   first bad:", list(zip(mm[:8], nn[:8])), "err", err[mm[:8], nn[:8]])
+
+sys.exit(1 if globals().get("FAIL", 0) else 0)
