@@ -263,6 +263,44 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(const float* __restrict__ 
   if (lane < V) logits[(size_t)r * V + lane] = mine;
 }
 
+// Few rows (a single chain samples 2 positions per iteration; generate_single ~50): the row-per-wave kernel above walks the 33
+// decoder rows one trip after the other (84 us for 2 rows).  Here one workgroup per row, one wave per 4 decoder rows: every wave
+// normalises the row itself (1280 values) and all decoder rows are in flight at once.
+__global__ __launch_bounds__(1024) void lm_tail_small_kernel(const float* __restrict__ g, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ embed,
+                                                            const float* __restrict__ out_bias, float* __restrict__ logits,
+                                                            int d, int V, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = blockIdx.x;
+  const int nch4 = d >> 2;
+  const float4* x4 = (const float4*)(g + (size_t)r * d);
+  float4 v[kMaxCh];
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
+  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  float s[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int t = wave * 4 + u < V ? wave * 4 + u : V - 1;
+    const float4* e4 = (const float4*)(embed + (size_t)t * d);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxCh; ++i)
+      if (lane + 64 * i < nch4) {
+        const float4 e = e4[lane + 64 * i];
+        a += (v[i].x * e.x + v[i].y * e.y) + (v[i].z * e.z + v[i].w * e.w);      // same per-lane order as lm_tail_kernel
+      }
+    s[u] = a;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float tot = wave_sum(s[u]);
+    const int t = wave * 4 + u;
+    if (t < V && lane == 0) logits[(size_t)r * V + t] = tot + out_bias[t];
+  }
+}
+
 // ---- strict mode helpers: fp32 -> (hi, lo) bf16 pair, optionally through erf-GELU ----------------
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -362,6 +400,12 @@ int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const floa
                    const float* out_bias, float* logits, int64_t n, int d, int V, float eps) {
   if (V > 64) return fail(1, "lm_tail: vocab > 64 unsupported");
   if (n == 0) return 0;
+  if (n <= 128) {        // identical arithmetic per logit (same per-lane partial sums, same wave reduction): bit-equal results
+    hipLaunchKernelGGL(lm_tail_small_kernel, dim3((unsigned)n), dim3(64 * ((V + 3) / 4)), 0, s, g, gamma, beta, embed, out_bias, logits,
+                       d, V, eps);
+    PG_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(lm_tail_kernel, dim3(rows_grid(n)), dim3(256), 0, s, g, gamma, beta, embed, out_bias, logits, n, d, V,
                      eps);
   PG_HIP(hipGetLastError());

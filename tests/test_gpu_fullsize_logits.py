@@ -85,3 +85,53 @@ def test_msa1b_full_size_all_logits(msa_case, precision):
         assert agree > 0.999            # flips only between near-tied logits (gap < 2e-3)
     else:
         assert err.max() < BF16_REL * want.std() and agree > 0.97
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config1_full_size_single_chain(esm_case, precision):
+    """BASELINE configuration 1 on the REAL ESM-1b shape: one chain of L = 25 (T = 27 tokens), 20 iterations, 10 % of the positions
+    (P = 2) per iteration, top_k = 1, burnin = 10 -- the weight-streaming (skinny GEMM) + hipGraph regime of the engine.  Every
+    iteration: positions == `random.sample`, the logits the engine sampled from == the fp32 oracle's logits for the engine's own
+    masked token buffer, every draw replays bit-exactly from those logits, and the write-back is what the loop says."""
+    import random
+    from oracle import draw as odraw
+    from protein_gibbs_sampler_amd import esm_sampler
+    cfg, sd, _, _ = esm_case
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = models.ESM1b(state_dict=sd, config=cfg, precision=precision)
+    s = esm_sampler.ESM_sampler(model, device="cuda:0")
+    seed = "MEPAATGQEAEECAHSGRGEAWEEV"
+    kw = dict(batch_size=1, num_iters=20, burnin=10, mask=True, in_order=False, num_positions_percent=10, top_k=1,
+              show_progress_bar=False)
+    s.draw_seed, s.record = 21, True
+    random.seed(0)
+    out = s.generate(1, seed, **kw)
+    run = s.last_run[0]
+    random.seed(0)
+    table = np.asarray([[random.sample(range(1, 26), 2)] for _ in range(20)])
+    assert (run["table"] == table).all()
+    tok = s.get_init_seq(seed, 25, 1).numpy().astype(np.int32)
+    ocfg = EsmConfig()
+    worst = 0.0
+    for it in range(20):
+        tin = tok.copy()
+        tin[0, table[it, 0]] = 32
+        ref = esm1b_forward(sd, ocfg, tin)[0, table[it, 0]]
+        rows = run["sampled_logits"][it].reshape(-1, 33)
+        worst = max(worst, float(np.abs(rows - ref).max()))
+        want = odraw.draw_rows(rows, s.valid_aa_idx, 1, it < 10, None, [0, 0], it, [0, 1], 0, 21)
+        assert (want == run["sampled_tokens"][it].reshape(-1)).all()
+        tok[0, table[it, 0]] = want
+    print("\n[config 1, ESM-1b 33 x 1280, %s] max|engine - oracle| over 20 iterations = %.3e" % (precision, worst))
+    assert worst < (STRICT_TOL if precision == "fp32" else BF16_REL * 10.0)
+    assert (tok == run["tokens"]).all() and out == s.untokenize_batch(torch_from(tok), True, True)
+    # the unrecorded run replays the loop from one captured hipGraph: same strings
+    s.record = False
+    random.seed(0)
+    assert s.generate(1, seed, **kw) == out
+
+
+def torch_from(a):
+    import torch
+    return torch.from_numpy(a.astype(np.int64))
