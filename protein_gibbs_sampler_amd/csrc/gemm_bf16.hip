@@ -516,9 +516,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 // without any epilogue at 1245-1273 TFLOP/s.
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, int abl = 0) {
-  // the big-tile kernel of the default dispatch: PGIBBS_GEMM_BIG=w4 the 4-wave kernel of gemm_w4.hip, default (pp) this one
-  static const bool use_w4 = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return e && e[0] == 'w'; }();
-  if (!abl && use_w4 && K >= 128) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
+  // the big-tile kernel of the default dispatch: PGIBBS_GEMM_BIG=w4 / w16: the 4-wave / 16-wave kernel of gemm_w4.hip / gemm_w16.hip, default (pp) this one
+  static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? 0 : (e[0] == 'w' ? (e[1] == '1' ? 16 : 4) : 0); }();
+  if (!abl && big == 4 && K >= 128) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
+  if (!abl && big == 16) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles), block(512);
   if (abl) {   // ablations: EPI_BF16 only
@@ -797,6 +798,7 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   if (M % 128 || N % 64) return fail(1, "gemm: M must be a multiple of 128 and N of 64");
   const bool ok256 = M % 256 == 0 && N % 256 == 0 && K >= 128, ok128 = N % 128 == 0;
   const long t256 = (long)(M / 256) * (N / 256), t128 = (long)(M / 128) * (N / 128);
+  if (variant >= 80 && ok256) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 80);
   if (variant >= 60 && ok256) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 40);   // pp ablations 20..
   if (variant >= 40 && ok256) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 40);
   if (variant >= 20 && ok256) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);

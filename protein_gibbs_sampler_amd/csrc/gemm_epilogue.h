@@ -1,0 +1,174 @@
+// Pieces shared by the 256 x 256 tile kernels of gemm_w4.hip (4 waves) and gemm_w16.hip (16 waves): vector types, the GELU
+// forms of gemm_bf16.hip, and the LDS-staged epilogue.
+#pragma once
+#include "kernels.h"
+
+namespace pg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+#define PG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define PG_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PG_NT_STORE(p, v) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(p))
+
+__device__ __forceinline__ float w4_gelu_erf(float x) {           // as gelu_erf in gemm_bf16.hip (fp32 outputs)
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = 1.0f - p * t * __expf(-z * z);
+  return 0.5f * x + 0.5f * fabsf(x) * e;
+}
+__device__ __forceinline__ float w4_gelu_bf16out(float x) {       // as gelu_bf16out in gemm_bf16.hip (bf16 outputs)
+  const float t = fabsf(x);
+  float p = -4.074793151e-04f;
+  p = fmaf(p, t, 6.563348950e-03f);
+  p = fmaf(p, t, -5.032995553e-02f);
+  p = fmaf(p, t, -4.618885100e-01f);
+  p = fmaf(p, t, -1.149779793e+00f);
+  p = fmaf(p, t, -1.000206717e+00f);
+  return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
+}
+
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of a 256 x 256 tile held by NW waves (4 or 16).  A lane holds 256 / NW "elements": four consecutive output features
+// (n) of one token row (m).  elem(e, m_loc, n_loc) returns element e (compile-time after unrolling) and its position inside the
+// tile.  The tile leaves through the (then idle) LDS so that every store instruction writes whole 512-B / 1-KiB output rows.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int EPI, int NW = 4, typename ElemF>
+__device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, int lane, int m0, int n0,
+                                            const float* __restrict__ bias, void* __restrict__ out, int ldo) {
+  constexpr int NE = 256 / NW;                   // elements per lane
+  constexpr int RB = 256 / NW;                   // bf16 pass: tile rows owned by a wave
+  constexpr int RF = 128 / NW;                   // fp32 passes: staged rows owned by a wave
+  __syncthreads();                               // every wave is done with the operand ring
+  if (EPI == EPI_BF16) {
+    // one pass: the whole 256 x 256 bf16 tile (128 KB) as 256 rows of 512 B, chunk-swizzled by row
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int row, n;
+      const f32x4 a = elem(e, row, n);
+      const float4 b4 = *(const float4*)(bias + n0 + n);
+      uint2 p;
+      p.x = pack_bf16x2(a[0] + b4.x, a[1] + b4.y);
+      p.y = pack_bf16x2(a[2] + b4.z, a[3] + b4.w);
+      *(uint2*)(smem + row * 512 + (((n >> 3) ^ (row & 31)) << 4) + (n & 4) * 2) = p;
+    }
+    __syncthreads();
+    const int c = lane & 31;
+    bf16_t* ob = (bf16_t*)out + (size_t)(m0 + wave * RB) * ldo + n0 + c * 8;
+#pragma unroll
+    for (int it = 0; it < RB / 2; ++it) {
+      const int row = wave * RB + it * 2 + (lane >> 5);
+      const uint4 v = *(const uint4*)(smem + row * 512 + ((c ^ (row & 31)) << 4));
+      PG_NT_STORE((uint4*)(ob + (size_t)(it * 2 + (lane >> 5)) * ldo), v);
+    }
+    return;
+  }
+  // fp32 staging, two passes of 128 token rows x 1 KiB: pass p takes the elements whose token row has bit 6 == p (64 rows of
+  // each 128-row half of the tile); wave w then owns the staged rows w*RF .. w*RF + RF-1 = token rows grow(p) .. grow(p) + RF-1
+  auto stage = [&](int p) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int row, n;
+      const f32x4 a = elem(e, row, n);
+      if (((row >> 6) & 1) != p) continue;       // row bit 6 is the same for all lanes of element e: wave-uniform, folds away
+      const float4 b4 = *(const float4*)(bias + n0 + n);
+      const int sr = (row >> 7) * 64 + (row & 63);
+      float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+      if (EPI == EPI_F32_GELU) { v.x = w4_gelu_erf(v.x); v.y = w4_gelu_erf(v.y); v.z = w4_gelu_erf(v.z); v.w = w4_gelu_erf(v.w); }
+      *(float4*)(smem + sr * 1024 + (((n >> 2) ^ (sr & 63)) << 4)) = v;
+    }
+  };
+  // staged row sr <-> token row (sr >> 6) * 128 + p * 64 + (sr & 63); a wave's RF rows never straddle a 64-row block
+  auto grow = [&](int p) { return m0 + ((wave * RF) >> 6) * 128 + p * 64 + ((wave * RF) & 63); };
+  if (EPI == EPI_BF16_GELU) {
+    const int c8 = lane & 31;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p) __syncthreads();
+      stage(p);
+      __syncthreads();
+      bf16_t* ob = (bf16_t*)out + (size_t)grow(p) * ldo + n0 + c8 * 8;
+#pragma unroll
+      for (int it = 0; it < RF / 2; ++it) {
+        const int r2 = it * 2 + (lane >> 5), sr = wave * RF + r2;
+        const float4 a = *(const float4*)(smem + sr * 1024 + (((2 * c8) ^ (sr & 63)) << 4));
+        const float4 b = *(const float4*)(smem + sr * 1024 + (((2 * c8 + 1) ^ (sr & 63)) << 4));
+        uint4 v;
+        v.x = pack_bf16x2(w4_gelu_bf16out(a.x), w4_gelu_bf16out(a.y));
+        v.y = pack_bf16x2(w4_gelu_bf16out(a.z), w4_gelu_bf16out(a.w));
+        v.z = pack_bf16x2(w4_gelu_bf16out(b.x), w4_gelu_bf16out(b.y));
+        v.w = pack_bf16x2(w4_gelu_bf16out(b.z), w4_gelu_bf16out(b.w));
+        PG_NT_STORE((uint4*)(ob + (size_t)r2 * ldo), v);
+      }
+    }
+    return;
+  }
+  if (EPI == EPI_F32_RESID) {
+    // out += tile: whole 1-KiB rows through buffer ops (wave-uniform row base, lane*16 offset); the row loads of the next
+    // half of a wave's rows are in flight while the previous half is added and stored
+    constexpr int HR = RF / 2;
+    const int rstep = ldo * 4, voff = lane * 16;
+    auto rs = [&](int p) { return __builtin_amdgcn_make_buffer_rsrc((float*)out + (size_t)grow(p) * ldo + n0, 0, 0x7fffffff, 0x00020000); };
+    auto ldh = [&](f32x4 (&r)[HR], rsrc_t s, int first) {
+#pragma unroll
+      for (int it = 0; it < HR; ++it)
+        r[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s, voff + (first + it) * rstep, 0, 2));
+    };
+    auto sth = [&](f32x4 (&r)[HR], rsrc_t s, int first) {
+#pragma unroll
+      for (int it = 0; it < HR; ++it) {
+        const int sr = wave * RF + first + it;
+        const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, r[it] + v), s, voff + (first + it) * rstep, 0, 2);
+      }
+    };
+    const rsrc_t rs0 = rs(0), rs1 = rs(1);
+    f32x4 ra[HR], rb[HR];
+    ldh(ra, rs0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldh(rb, rs0, HR);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    sth(ra, rs0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldh(ra, rs1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    sth(rb, rs0, HR);
+    __builtin_amdgcn_sched_barrier(0);
+    ldh(rb, rs1, HR);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    stage(1);
+    __syncthreads();
+    sth(ra, rs1, 0);
+    sth(rb, rs1, HR);
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {                  // EPI_F32, EPI_F32_GELU
+    if (p) __syncthreads();
+    stage(p);
+    __syncthreads();
+    float* ob = (float*)out + (size_t)grow(p) * ldo + n0 + lane * 4;
+#pragma unroll
+    for (int it = 0; it < RF; ++it) {
+      const int sr = wave * RF + it;
+      const float4 v = *(const float4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
+      PG_NT_STORE((float4*)(ob + (size_t)it * ldo), v);
+    }
+  }
+}
+
+}  // namespace pg

@@ -28,6 +28,10 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
 int launch_gemm_w4(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                    int ldw, int ldo, int epi, int abl = 0);
 
+// the 16-wave 256x256 tile kernel (gemm_w16.hip): same contract
+int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
+                    int ldw, int ldo, int epi, int abl = 0);
+
 // fused attention, one (sequence, head) per workgroup; qkv rows are [q | k | v] with head h at h*64
 // key_tok (optional): the int32 token buffer [n_seq][T]; keys whose token is pad_idx are masked (ragged batches)
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,

@@ -13,7 +13,7 @@ def bf16(a):
 L = _lib.lib()
 CASES = [(512, 256, 64, 0), (512, 256, 128, 0), (512, 512, 256, 0), (512, 512, 512, 0), (512, 512, 1280, 0),
          (256, 256, 256, 3), (2048, 1024, 320, 2), (256, 256, 256, 1), (256, 256, 256, 4)]
-if os.environ["PGIBBS_GEMM"] not in ("40", "51"):
+if os.environ["PGIBBS_GEMM"] not in ("40", "51", "80"):
     CASES = [c for c in CASES if c[3] == 3]        # ablation variants exist for the bf16 epilogue only
     CASES += [(256, 256, 320, 3), (512, 512, 1280, 3)]
 for (M, N, K, epi) in CASES:
