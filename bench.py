@@ -102,7 +102,7 @@ def measured_gemm_traffic():
         return None, None
     k = json.load(open(paths[-1]))["kernels"]
     gem = [(v["launches"], v["read_MB_per_launch"] + v["write_MB_per_launch"]) for n, v in k.items()
-           if any(t in n for t in ("gemm_bf16_pp_kernel", "gemm_bf16_w4_kernel"))]      # the big-tile kernels (not the peeled panels)
+           if any(t in n for t in ("gemm_bf16_pp_kernel", "gemm_bf16_w4_kernel", "gemm_bf16_w16_kernel"))]      # the big-tile kernels (not the peeled panels)
     if not gem:
         return None, os.path.basename(paths[-1])
     return 1e6 * sum(n * mb for n, mb in gem) / sum(n for n, _ in gem), os.path.basename(paths[-1])

@@ -517,9 +517,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, int abl = 0) {
   // the big-tile kernel of the default dispatch: PGIBBS_GEMM_BIG=w4 / w16: the 4-wave / 16-wave kernel of gemm_w4.hip / gemm_w16.hip, default (pp) this one
-  static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? 0 : (e[0] == 'w' ? (e[1] == '1' ? 16 : 4) : 0); }();
+  // -1 (default): per shape -- the 16-wave kernel for the plain bf16 epilogue (QKV projections: 3.5-4 % faster there), this one
+  // for the rest (the 16-wave kernel loses 3-4 % on the N = d residual GEMMs); 0 = always this one, 4 / 16 = always that kernel
+  static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? (e[1] == '1' ? 16 : 4) : 0); }();
   if (!abl && big == 4 && K >= 128) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
-  if (!abl && big == 16) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
+  if (!abl && (big == 16 || (big == -1 && epi == EPI_BF16))) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles), block(512);
   if (abl) {   // ablations: EPI_BF16 only
