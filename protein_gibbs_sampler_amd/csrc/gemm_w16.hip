@@ -18,7 +18,9 @@
 // Measured and removed again (QKV shape, this kernel 0.551-0.560 ms, the 8-wave ping-pong kernel 0.571-0.579): no barrier at all
 // (timing only) 0.537; DMA never waited for 0.583 (= real: latency is covered); DMA pieces behind the first fragment reads, s_setprio
 // around the MFMA clusters: no change; the barrier moved between the reads and the MFMAs of the second half-step (so that a released
-// wave still has 16 MFMAs queued): 0.560-0.567; a 16-wave port of the two-group ping-pong schedule (4 barriers per K-step): 0.582.
+// wave still has 16 MFMAs queued): 0.560-0.567; a 16-wave port of the two-group ping-pong schedule (4 barriers per K-step): 0.582;
+// waves 8-15 skewed half a K-step behind waves 0-7 with still one barrier per K-step (their barrier between the reads and MFMAs of the
+// second half-step, so that one group issues MFMAs from registers while the other restarts with LDS reads): 0.546 vs 0.552.
 #include <stdlib.h>
 
 #include "gemm_epilogue.h"
