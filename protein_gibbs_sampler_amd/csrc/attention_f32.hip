@@ -7,8 +7,29 @@
 
 namespace pg {
 
-__global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ ctx_hi,
-                                                          bf16_t* __restrict__ ctx_lo, int T, int H, int ld_qkv_,
+// One thread's 64 context values of head h -> bf16 at dst (already offset to the head's columns).  split_d > 0: the row is
+// the strict mode's K-concatenated operand [lo | hi | hi] (3 * split_d wide, elementwise.hip store_row_bf16).
+__device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf16_t* dst, int split_d) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float a = o[4 * i] * inv, b = o[4 * i + 1] * inv, c = o[4 * i + 2] * inv, d = o[4 * i + 3] * inv;
+    uint2 p, r;
+    p.x = pack_bf16x2(a, b);
+    p.y = pack_bf16x2(c, d);
+    if (!split_d) {
+      ((uint2*)dst)[i] = p;
+    } else {
+      r.x = pack_bf16x2(a - bf16_to_f32((bf16_t)(p.x & 0xffff)), b - bf16_to_f32((bf16_t)(p.x >> 16)));
+      r.y = pack_bf16x2(c - bf16_to_f32((bf16_t)(p.y & 0xffff)), d - bf16_to_f32((bf16_t)(p.y >> 16)));
+      ((uint2*)dst)[i] = r;
+      ((uint2*)(dst + split_d))[i] = p;
+      ((uint2*)(dst + 2 * split_d))[i] = p;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                          int split_d, int T, int H, int ld_qkv_,
                                                           int ld_ctx_, int k_off, int v_off, SeqLayout sl, int n_qchunk,
                                                           const int32_t* __restrict__ key_tok, int pad_idx) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * 64];
@@ -86,22 +107,7 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
     }
     m = mn;
   }
-  if (valid) {
-    const float inv = 1.0f / l;
-    bf16_t* dh = ctx_hi + row0 * ld_ctx_ + (size_t)qi * ld_ctx + h * 64;
-    bf16_t* dl = ctx_lo + row0 * ld_ctx_ + (size_t)qi * ld_ctx + h * 64;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float a = o[4 * i] * inv, b = o[4 * i + 1] * inv, c = o[4 * i + 2] * inv, d = o[4 * i + 3] * inv;
-      uint2 p, r;
-      p.x = pack_bf16x2(a, b);
-      p.y = pack_bf16x2(c, d);
-      r.x = pack_bf16x2(a - bf16_to_f32((bf16_t)(p.x & 0xffff)), b - bf16_to_f32((bf16_t)(p.x >> 16)));
-      r.y = pack_bf16x2(c - bf16_to_f32((bf16_t)(p.y & 0xffff)), d - bf16_to_f32((bf16_t)(p.y >> 16)));
-      ((uint2*)dh)[i] = p;
-      ((uint2*)dl)[i] = r;
-    }
-  }
+  if (valid) store_ctx64(o, 1.0f / l, ctx + row0 * ld_ctx_ + (size_t)qi * ld_ctx + h * 64, split_d);
 }
 
 // ---- strict tied row attention (MSA): S = scale * sum_r q_r k_r^T (fp32, to a scratch buffer), then
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64) void msa_row_scores_f32_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(64) void msa_row_apply_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ S,
-                                                              bf16_t* __restrict__ ctx_hi, bf16_t* __restrict__ ctx_lo, int R,
+                                                              bf16_t* __restrict__ ctx, int split_d, int R,
                                                               int C, int H, int ld_qkv, int ld_ctx, int v_off, int n_chunk) {
   __shared__ __attribute__((aligned(16))) float Vs[64 * 64];
   const int lane = threadIdx.x;
@@ -197,42 +203,28 @@ __global__ __launch_bounds__(64) void msa_row_apply_f32_kernel(const float* __re
       }
     }
   }
-  if (valid) {
-    const float inv = 1.0f / l;
-    const size_t off = (((size_t)b * R + r) * C + qi) * ld_ctx + h * 64;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float a = o[4 * i] * inv, b2 = o[4 * i + 1] * inv, c = o[4 * i + 2] * inv, d = o[4 * i + 3] * inv;
-      uint2 p, q;
-      p.x = pack_bf16x2(a, b2);
-      p.y = pack_bf16x2(c, d);
-      q.x = pack_bf16x2(a - bf16_to_f32((bf16_t)(p.x & 0xffff)), b2 - bf16_to_f32((bf16_t)(p.x >> 16)));
-      q.y = pack_bf16x2(c - bf16_to_f32((bf16_t)(p.y & 0xffff)), d - bf16_to_f32((bf16_t)(p.y >> 16)));
-      ((uint2*)(ctx_hi + off))[i] = p;
-      ((uint2*)(ctx_lo + off))[i] = q;
-    }
-  }
+  if (valid) store_ctx64(o, 1.0f / l, ctx + (((size_t)b * R + r) * C + qi) * ld_ctx + h * 64, split_d);
 }
 
-int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx_hi, bf16_t* ctx_lo, int B, int R,
+int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx, int split_d, int B, int R,
                                  int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale) {
   if (B == 0 || R == 0) return 0;
   const int n_chunk = (C + 63) / 64;
   hipLaunchKernelGGL(msa_row_scores_f32_kernel, dim3((unsigned)(B * H * n_chunk * n_chunk)), dim3(64), 0, s, qkv, scores, R, C, H,
                      ld_qkv, k_off, scale, n_chunk);
-  hipLaunchKernelGGL(msa_row_apply_f32_kernel, dim3((unsigned)(B * H * R * n_chunk)), dim3(64), 0, s, qkv, scores, ctx_hi, ctx_lo,
+  hipLaunchKernelGGL(msa_row_apply_f32_kernel, dim3((unsigned)(B * H * R * n_chunk)), dim3(64), 0, s, qkv, scores, ctx, split_d,
                      R, C, H, ld_qkv, ld_ctx, v_off, n_chunk);
   PG_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx_hi, bf16_t* ctx_lo, int64_t n_seq, int T, int H,
+int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split_d, int64_t n_seq, int T, int H,
                          int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx) {
   if (n_seq == 0) return 0;
   if (T <= 0) return fail(1, "attention: empty sequence");
   const int n_qchunk = (T + 63) / 64;
   if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
-  hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), dim3(64), 0, s, qkv, ctx_hi, ctx_lo, T, H,
+  hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), dim3(64), 0, s, qkv, ctx, split_d, T, H,
                      ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx);
   PG_HIP(hipGetLastError());
   return 0;

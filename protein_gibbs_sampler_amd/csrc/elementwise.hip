@@ -55,21 +55,25 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[kMaxCh], int nch4, int la
     }
 }
 
-// hi = bf16(v); optional lo = bf16(v - hi): the split-bf16 ("bf16x3") operand pair of the strict precision mode
-__device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane,
-                                               bf16_t* dst_lo = nullptr) {
+// hi = bf16(v).  split3 (strict precision mode): the row is the K-concatenated split-bf16 activation operand
+// [lo | hi | hi] of 3 * d values with lo = bf16(v - hi); against a weight row packed [hi | lo | hi] one bf16 GEMM over
+// K = 3 d sums  x_lo.w_hi + x_hi.w_lo + x_hi.w_hi  (small terms first) in its fp32 accumulator.
+__device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane, bool split3 = false) {
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) {
       uint2 p;
       p.x = pack_bf16x2(v[i].x, v[i].y);
       p.y = pack_bf16x2(v[i].z, v[i].w);
-      ((uint2*)dst)[lane + 64 * i] = p;
-      if (dst_lo) {
+      if (!split3) {
+        ((uint2*)dst)[lane + 64 * i] = p;
+      } else {
         uint2 q;
         q.x = pack_bf16x2(v[i].x - bf16_to_f32((bf16_t)(p.x & 0xffff)), v[i].y - bf16_to_f32((bf16_t)(p.x >> 16)));
         q.y = pack_bf16x2(v[i].z - bf16_to_f32((bf16_t)(p.y & 0xffff)), v[i].w - bf16_to_f32((bf16_t)(p.y >> 16)));
-        ((uint2*)dst_lo)[lane + 64 * i] = q;
+        ((uint2*)dst)[lane + 64 * i] = q;
+        ((uint2*)dst)[nch4 + lane + 64 * i] = p;
+        ((uint2*)dst)[2 * nch4 + lane + 64 * i] = p;
       }
     }
 }
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
 // ---- LayerNorm: x fp32 [M][d] -> h bf16 [M][d] ------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ h,
-                                                            bf16_t* __restrict__ h_lo, int64_t M, int d, float eps) {
+                                                            int split3, int64_t M, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
   ln_inplace(v, nch4, lane, d, eps, gamma, beta);
-  store_row_bf16(h + (size_t)row * d, v, nch4, lane, h_lo ? h_lo + (size_t)row * d : nullptr);
+  store_row_bf16(h + (size_t)row * d * (split3 ? 3 : 1), v, nch4, lane, split3);
 }
 
 // fp32 -> fp32 LayerNorm (debug entry / strict paths)
@@ -174,8 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
 __global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                             const int32_t* __restrict__ row_map, int P, int width,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            bf16_t* __restrict__ h, bf16_t* __restrict__ h_lo, int64_t n_sel,
-                                                            int d, float eps) {
+                                                            bf16_t* __restrict__ h, int split3, int64_t n_sel, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_sel) return;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void gather_ln_bf16_kernel(const float* __rest
       if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
     ln_inplace(v, nch4, lane, d, eps, gamma, beta);
   }
-  store_row_bf16(h + (size_t)r * d, v, nch4, lane, h_lo ? h_lo + (size_t)r * d : nullptr);
+  store_row_bf16(h + (size_t)r * d * (split3 ? 3 : 1), v, nch4, lane, split3);
 }
 
 // ---- plain row gathers (last-layer pruning: only the sampled rows go through out-proj / FFN of the final layer) ----
@@ -304,9 +307,9 @@ __global__ __launch_bounds__(1024) void lm_tail_small_kernel(const float* __rest
 // ---- strict mode helpers: fp32 -> (hi, lo) bf16 pair, optionally through erf-GELU ----------------
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <bool GELU>
-__global__ void split_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int64_t n4,
-                                  float scale) {
+// src fp32 [rows][K] -> dst bf16 [rows][3K]: [lo | hi | hi] (activation operand) or, WEIGHT, [hi | lo | hi]
+template <bool GELU, bool WEIGHT>
+__global__ void split3_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4, int k4, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n4; i += stride) {
@@ -318,8 +321,11 @@ __global__ void split_bf16_kernel(const float* __restrict__ src, bf16_t* __restr
     p.y = pack_bf16x2(v.z, v.w);
     q.x = pack_bf16x2(v.x - bf16_to_f32((bf16_t)(p.x & 0xffff)), v.y - bf16_to_f32((bf16_t)(p.x >> 16)));
     q.y = pack_bf16x2(v.z - bf16_to_f32((bf16_t)(p.y & 0xffff)), v.w - bf16_to_f32((bf16_t)(p.y >> 16)));
-    ((uint2*)hi)[i] = p;
-    ((uint2*)lo)[i] = q;
+    const int64_t row = i / k4;
+    uint2* o = (uint2*)dst + row * 3 * k4 + (i - row * k4);
+    o[0] = WEIGHT ? p : q;
+    o[k4] = WEIGHT ? q : p;
+    o[2 * k4] = p;
   }
 }
 __global__ void gelu_f32_kernel(float* __restrict__ p, int64_t n) {
@@ -360,10 +366,10 @@ int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, co
 }
 
 int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
-                          int d, float eps, bf16_t* h_lo) {
+                          int d, float eps, bool split3) {
   if (d % 4 || d > kMaxCh * 256) return fail(1, "layernorm: d must be a multiple of 4 and <= 2048");
   if (M == 0) return 0;
-  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, h_lo, M, d, eps);
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, split3 ? 1 : 0, M, d, eps);
   PG_HIP(hipGetLastError());
   return 0;
 }
@@ -378,10 +384,10 @@ int launch_layernorm_f32(hipStream_t s, const float* x, const float* gamma, cons
 }
 
 int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, const int32_t* row_map, int P, int width,
-                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps, bf16_t* h_lo) {
+                          const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps, bool split3) {
   if (n_sel == 0) return 0;
   hipLaunchKernelGGL(gather_ln_bf16_kernel, dim3(rows_grid(n_sel)), dim3(256), 0, s, x, idx, row_map, P, width, gamma,
-                     beta, h, h_lo, n_sel, d, eps);
+                     beta, h, split3 ? 1 : 0, n_sel, d, eps);
   PG_HIP(hipGetLastError());
   return 0;
 }
@@ -412,13 +418,15 @@ int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const floa
   return 0;
 }
 
-int launch_split_bf16(hipStream_t s, const float* src, bf16_t* hi, bf16_t* lo, int64_t n, float scale, bool gelu) {
-  if (n == 0) return 0;
-  if (n % 4) return fail(1, "split: n must be a multiple of 4");
-  const int64_t n4 = n / 4;
+int launch_split3_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t rows, int K, float scale, bool gelu, bool weight) {
+  if (rows == 0) return 0;
+  if (K % 4) return fail(1, "split: K must be a multiple of 4");
+  const int64_t n4 = rows * (K / 4);
   const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-  if (gelu) hipLaunchKernelGGL(split_bf16_kernel<true>, dim3(grid), dim3(256), 0, s, src, hi, lo, n4, scale);
-  else hipLaunchKernelGGL(split_bf16_kernel<false>, dim3(grid), dim3(256), 0, s, src, hi, lo, n4, scale);
+  if (gelu && !weight) hipLaunchKernelGGL((split3_bf16_kernel<true, false>), dim3(grid), dim3(256), 0, s, src, dst, n4, K / 4, scale);
+  else if (!gelu && weight) hipLaunchKernelGGL((split3_bf16_kernel<false, true>), dim3(grid), dim3(256), 0, s, src, dst, n4, K / 4, scale);
+  else if (!gelu) hipLaunchKernelGGL((split3_bf16_kernel<false, false>), dim3(grid), dim3(256), 0, s, src, dst, n4, K / 4, scale);
+  else return fail(1, "split: GELU on a weight operand");
   PG_HIP(hipGetLastError());
   return 0;
 }

@@ -30,9 +30,8 @@ struct Prof {
 
 enum ProfClass { PC_GEMM = 0, PC_ATTN, PC_LN, PC_EMBED, PC_HEAD, PC_SAMPLE, PC_COUNT };
 
-struct DenseW {   // y = x W^T + b ; W bf16 [N][K], b fp32 [N]; w_lo = bf16(W - w) in the strict precision mode
-  bf16_t* w = nullptr;
-  bf16_t* w_lo = nullptr;
+struct DenseW {   // y = x W^T + b ; W bf16 [N][K], b fp32 [N].  Strict precision mode: w is [N][3K], each row the
+  bf16_t* w = nullptr;   // K-concatenated split-bf16 operand [hi | lo | hi] (hi = bf16(W), lo = bf16(W - hi))
   float* b = nullptr;
   int N = 0, K = 0;
 };
@@ -64,7 +63,6 @@ struct Engine {
 
   // workspace (grow-only)
   DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
-  // strict precision mode (PG_PREC_FP32): lo halves of the split-bf16 operands, fp32 GEMM outputs, row-attention scores
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask
@@ -74,10 +72,13 @@ struct Engine {
   DevBuf d_iter;
   hipGraphExec_t graph_exec = nullptr;
   std::vector<uint8_t> graph_key;
-  DevBuf h_lo, ctx_lo, ffn_lo, ffn_f32, sel_h_lo, scores, zero_bias;
+  // strict precision mode (PG_PREC_FP32): h, ctx, ffn, sel_h hold [lo | hi | hi] rows (3x wide); fp32 fc1 output;
+  // row-attention scores (also the bf16 mode's wide-alignment fallback)
+  DevBuf ffn_f32, scores;
   bool strict() const { return precision == PG_PREC_FP32; }
-  // out[Mp][N] fp32 (=|+=) X.W^T + b with X = xh + xl, W = w + w_lo:  xh.w + xh.w_lo + xl.w  (three MFMA GEMMs)
-  int dense3(const bf16_t* xh, const bf16_t* xl, const DenseW& W, float* out, int Mp, bool accumulate);
+  // out[Mp][N] fp32 (=|+=) X.W^T + b with X = xh + xl, W = wh + wl as ONE bf16 GEMM over K' = 3K:
+  // [xl | xh | xh] . [wh | wl | wh]^T = xl.wh + xh.wl + xh.wh  (the dropped xl.wl term is ~2^-17 relative)
+  int dense3(const bf16_t* x3, const DenseW& W, float* out, int Mp, bool accumulate);
   Prof prof;
 
   ~Engine();

@@ -92,7 +92,7 @@ Engine::~Engine() {
   if (device >= 0) (void)hipSetDevice(device);
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
-                    &d_rowmap, &scratch, &d_iter, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &h_lo, &ctx_lo, &ffn_lo, &ffn_f32, &sel_h_lo, &scores, &zero_bias, &splitk};
+                    &d_rowmap, &scratch, &d_iter, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
   for (DevBuf* b : bufs) b->release();
   prof.destroy();
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -121,23 +121,20 @@ struct Uploader {
   bool dense(DenseW& out, const std::vector<std::string>& prefixes, const std::vector<float>& scales, int n_each, int K) {
     const int parts = (int)prefixes.size();
     const int64_t N = (int64_t)n_each * parts;
-    void *dw = nullptr, *db = nullptr, *tmp = nullptr, *dlo = nullptr;
-    if (hipMalloc(&dw, (size_t)N * K * 2) != hipSuccess || hipMalloc(&db, (size_t)N * 4) != hipSuccess ||
+    void *dw = nullptr, *db = nullptr, *tmp = nullptr;
+    const int Kw = e->strict() ? 3 * K : K;      // strict: rows are [hi | lo | hi]
+    if (hipMalloc(&dw, (size_t)N * Kw * 2) != hipSuccess || hipMalloc(&db, (size_t)N * 4) != hipSuccess ||
         hipMalloc(&tmp, (size_t)n_each * K * 4) != hipSuccess) { err = "hipMalloc failed for " + prefixes[0]; return false; }
     e->owned.push_back(dw);
     e->owned.push_back(db);
-    if (e->strict()) {
-      if (hipMalloc(&dlo, (size_t)N * K * 2) != hipSuccess) { err = "hipMalloc failed for " + prefixes[0]; return false; }
-      e->owned.push_back(dlo);
-    }
     for (int p = 0; p < parts; ++p) {
       const float* w = tm->get(prefixes[p] + ".weight", (int64_t)n_each * K, err);
       const float* b = w ? tm->get(prefixes[p] + ".bias", n_each, err) : nullptr;
       if (!w || !b) { (void)hipFree(tmp); return false; }
       bool ok = hipMemcpy(tmp, w, (size_t)n_each * K * 4, hipMemcpyHostToDevice) == hipSuccess;
       if (e->strict())
-        ok = ok && launch_split_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * K,
-                                     (bf16_t*)dlo + (size_t)p * n_each * K, (int64_t)n_each * K, scales[p], false) == 0;
+        ok = ok && launch_split3_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * Kw, n_each, K, scales[p],
+                                      false, true) == 0;
       else
         ok = ok && launch_f32_to_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * K, (int64_t)n_each * K, scales[p]) == 0;
       ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
@@ -148,7 +145,6 @@ struct Uploader {
     }
     (void)hipFree(tmp);
     out.w = (bf16_t*)dw;
-    out.w_lo = (bf16_t*)dlo;
     out.b = (float*)db;
     out.N = (int)N;
     out.K = K;
@@ -180,11 +176,6 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
   PG_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
   stream = own_stream;
 
-  {
-    const int nz = cfg.d_ffn > 3 * cfg.d_model ? cfg.d_ffn : 3 * cfg.d_model;
-    int rcz = zero_bias.ensure((size_t)nz * 4, stream);   // zero-filled by ensure()
-    if (rcz) return rcz;
-  }
   TensorMap tm;
   for (int i = 0; i < n_tensors; ++i)
     if (tensors[i].name) tm.m[tensors[i].name] = &tensors[i];
@@ -234,14 +225,11 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
   return PG_OK;
 }
 
-// strict precision mode GEMM: three bf16 MFMA GEMMs reproduce an fp32 x fp32 product to ~2^-17 relative
-// (the dropped lo.lo term), accumulated in fp32 by the GEMM kernel's residual epilogue.
-int Engine::dense3(const bf16_t* xh, const bf16_t* xl, const DenseW& W, float* out, int Mp, bool accumulate) {
-  const float* zb = zero_bias.as<float>();
-  int rc;
-  if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, xh, W.w, W.b, out, Mp, W.N, W.K, W.K, W.K, W.N, accumulate ? EPI_F32_RESID : EPI_F32); }))) return rc;
-  if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, xh, W.w_lo, zb, out, Mp, W.N, W.K, W.K, W.K, W.N, EPI_F32_RESID); }))) return rc;
-  return timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, xl, W.w, zb, out, Mp, W.N, W.K, W.K, W.K, W.N, EPI_F32_RESID); });
+// strict precision mode GEMM: one bf16 MFMA GEMM over the K-concatenated split operands (engine.h) reproduces an
+// fp32 x fp32 product to ~2^-17 relative (the dropped lo.lo term); fp32 accumulation, small terms first.
+int Engine::dense3(const bf16_t* x3, const DenseW& W, float* out, int Mp, bool accumulate) {
+  const int K3 = 3 * W.K;
+  return timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, x3, W.w, W.b, out, Mp, W.N, K3, K3, K3, W.N, accumulate ? EPI_F32_RESID : EPI_F32); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -263,10 +251,10 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   int rc;
   if (strict()) {
     if ((rc = x.ensure((size_t)Mp * d * 4, stream))) return rc;
-    if ((rc = h.ensure((size_t)Mp * d * 2, stream)) || (rc = h_lo.ensure((size_t)Mp * d * 2, stream))) return rc;
+    if ((rc = h.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;        // [lo | hi | hi] rows
     if ((rc = qkv.ensure((size_t)Mp * 3 * d * 4, stream))) return rc;
-    if ((rc = ctx.ensure((size_t)Mp * d * 2, stream)) || (rc = ctx_lo.ensure((size_t)Mp * d * 2, stream))) return rc;
-    if ((rc = ffn.ensure((size_t)Mp * f * 2, stream)) || (rc = ffn_lo.ensure((size_t)Mp * f * 2, stream))) return rc;
+    if ((rc = ctx.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;
+    if ((rc = ffn.ensure((size_t)Mp * 3 * f * 2, stream))) return rc;
     if ((rc = ffn_f32.ensure((size_t)Mp * f * 4, stream))) return rc;
     float* X = x.as<float>();
     float* QKVf = qkv.as<float>();
@@ -280,14 +268,14 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     const SeqLayout chain = {1, T, 0, 1};
     for (int l = 0; l < cfg.n_layers; ++l) {
       const EsmLayer& L = esm_layers[l];
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, h_lo.as<bf16_t>()); }))) return rc;
-      if ((rc = dense3(h.as<bf16_t>(), h_lo.as<bf16_t>(), L.qkv, QKVf, Mi, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), ctx_lo.as<bf16_t>(), B, T, cfg.n_heads, 3 * d, d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
-      if ((rc = dense3(ctx.as<bf16_t>(), ctx_lo.as<bf16_t>(), L.out, X, Mi, true))) return rc;
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, h_lo.as<bf16_t>()); }))) return rc;
-      if ((rc = dense3(h.as<bf16_t>(), h_lo.as<bf16_t>(), L.fc1, ffn_f32.as<float>(), Mi, false))) return rc;
-      if ((rc = timed(PC_LN, [&] { return launch_split_bf16(stream, ffn_f32.as<float>(), ffn.as<bf16_t>(), ffn_lo.as<bf16_t>(), (int64_t)Mp * f, 1.f, true); }))) return rc;
-      if ((rc = dense3(ffn.as<bf16_t>(), ffn_lo.as<bf16_t>(), L.fc2, X, Mi, true))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
+      if ((rc = dense3(h.as<bf16_t>(), L.qkv, QKVf, Mi, false))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), d, B, T, cfg.n_heads, 3 * d, 3 * d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
+      if ((rc = dense3(ctx.as<bf16_t>(), L.out, X, Mi, true))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
+      if ((rc = dense3(h.as<bf16_t>(), L.fc1, ffn_f32.as<float>(), Mi, false))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_split3_bf16(stream, ffn_f32.as<float>(), ffn.as<bf16_t>(), Mp, f, 1.f, true, false); }))) return rc;
+      if ((rc = dense3(ffn.as<bf16_t>(), L.fc2, X, Mi, true))) return rc;
     }
     return PG_OK;
   }
@@ -353,10 +341,10 @@ int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int wid
   if ((rc = sel_g.ensure((size_t)Np * d * 4, stream))) return rc;
   const float eps = cfg.layer_norm_eps;
   if (strict()) {
-    if ((rc = sel_h_lo.ensure((size_t)Np * d * 2, stream))) return rc;
+    if ((rc = sel_h.ensure((size_t)Np * 3 * d * 2, stream))) return rc;
     if ((rc = launch_gather_ln_bf16(stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
-                                    sel_h.as<bf16_t>(), n_sel, d, eps, sel_h_lo.as<bf16_t>()))) return rc;
-    if ((rc = dense3(sel_h.as<bf16_t>(), sel_h_lo.as<bf16_t>(), head_dense, sel_g.as<float>(), (int)Np, false))) return rc;
+                                    sel_h.as<bf16_t>(), n_sel, d, eps, true))) return rc;
+    if ((rc = dense3(sel_h.as<bf16_t>(), head_dense, sel_g.as<float>(), (int)Np, false))) return rc;
     if ((rc = launch_gelu_f32(stream, sel_g.as<float>(), Np * d))) return rc;
     return launch_lm_tail(stream, sel_g.as<float>(), head_ln.g, head_ln.b, embed, head_bias, d_logits, n_sel, d, V, eps);
   }
@@ -464,13 +452,13 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   const int Mi = (int)Mp;
   const float row_scale = 0.125f / sqrtf((float)R);      // dh^-0.5 / sqrt(R): depends on R, applied to the scores
   if (strict()) {
-    if ((rc = h_lo.ensure((size_t)Mp * d * 2, stream)) || (rc = ctx_lo.ensure((size_t)Mp * d * 2, stream))) return rc;
+    if ((rc = h.ensure((size_t)Mp * 3 * d * 2, stream)) || (rc = ctx.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;   // [lo | hi | hi] rows
     if ((rc = qkv.ensure((size_t)Mp * 3 * d * 4, stream))) return rc;
-    if ((rc = ffn_lo.ensure((size_t)Mp * f * 2, stream)) || (rc = ffn_f32.ensure((size_t)Mp * f * 4, stream))) return rc;
+    if ((rc = ffn.ensure((size_t)Mp * 3 * f * 2, stream)) || (rc = ffn_f32.ensure((size_t)Mp * f * 4, stream))) return rc;
     if ((rc = scores.ensure((size_t)B * H * C * C * 4, stream))) return rc;
     float* Xs = x.as<float>();
     float* QKVf = qkv.as<float>();
-    bf16_t *Hh2 = h.as<bf16_t>(), *Hl2 = h_lo.as<bf16_t>(), *Ch = ctx.as<bf16_t>(), *Cl = ctx_lo.as<bf16_t>();
+    bf16_t *H3 = h.as<bf16_t>(), *C3 = ctx.as<bf16_t>();
     const float eps2 = cfg.layer_norm_eps;
     const int Mi2 = (int)Mp;
     rc = timed(PC_EMBED, [&] {
@@ -481,18 +469,18 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     const SeqLayout colS = {C, R * C, 1, C};
     for (int l = 0; l < cfg.n_layers; ++l) {
       const MsaLayer& L = msa_layers[l];
-      if ((rc = launch_layernorm_bf16(stream, Xs, L.ln_row.g, L.ln_row.b, Hh2, M, d, eps2, Hl2))) return rc;
-      if ((rc = dense3(Hh2, Hl2, L.row_qkv, QKVf, Mi2, false))) return rc;
-      if ((rc = launch_msa_row_attention_f32(stream, QKVf, scores.as<float>(), Ch, Cl, B, R, C, H, 3 * d, d, d, 2 * d, row_scale))) return rc;
-      if ((rc = dense3(Ch, Cl, L.row_out, Xs, Mi2, true))) return rc;
-      if ((rc = launch_layernorm_bf16(stream, Xs, L.ln_col.g, L.ln_col.b, Hh2, M, d, eps2, Hl2))) return rc;
-      if ((rc = dense3(Hh2, Hl2, L.col_qkv, QKVf, Mi2, false))) return rc;
-      if ((rc = launch_attention_f32(stream, QKVf, Ch, Cl, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, colS))) return rc;
-      if ((rc = dense3(Ch, Cl, L.col_out, Xs, Mi2, true))) return rc;
-      if ((rc = launch_layernorm_bf16(stream, Xs, L.ln_ffn.g, L.ln_ffn.b, Hh2, M, d, eps2, Hl2))) return rc;
-      if ((rc = dense3(Hh2, Hl2, L.fc1, ffn_f32.as<float>(), Mi2, false))) return rc;
-      if ((rc = launch_split_bf16(stream, ffn_f32.as<float>(), ffn.as<bf16_t>(), ffn_lo.as<bf16_t>(), (int64_t)Mp * f, 1.f, true))) return rc;
-      if ((rc = dense3(ffn.as<bf16_t>(), ffn_lo.as<bf16_t>(), L.fc2, Xs, Mi2, true))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, Xs, L.ln_row.g, L.ln_row.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = dense3(H3, L.row_qkv, QKVf, Mi2, false))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_f32(stream, QKVf, scores.as<float>(), C3, d, B, R, C, H, 3 * d, 3 * d, d, 2 * d, row_scale); }))) return rc;
+      if ((rc = dense3(C3, L.row_out, Xs, Mi2, true))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, Xs, L.ln_col.g, L.ln_col.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = dense3(H3, L.col_qkv, QKVf, Mi2, false))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, C3, d, (int64_t)B * C, R, H, 3 * d, 3 * d, d, 2 * d, colS); }))) return rc;
+      if ((rc = dense3(C3, L.col_out, Xs, Mi2, true))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, Xs, L.ln_ffn.g, L.ln_ffn.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = dense3(H3, L.fc1, ffn_f32.as<float>(), Mi2, false))) return rc;
+      if ((rc = timed(PC_LN, [&] { return launch_split3_bf16(stream, ffn_f32.as<float>(), ffn.as<bf16_t>(), Mp, f, 1.f, true, false); }))) return rc;
+      if ((rc = dense3(ffn.as<bf16_t>(), L.fc2, Xs, Mi2, true))) return rc;
     }
     return PG_OK;
   }
@@ -517,12 +505,11 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0); }))) return rc;
     } else {
       // alignments wider than the MFMA row-attention kernel's register budget: fp32 scores through a scratch buffer
-      if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * C * 4, stream)) ||
-          (rc = ctx_lo.ensure((size_t)Mp * d * 2, stream))) return rc;
+      if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * C * 4, stream))) return rc;
       rc = timed(PC_ATTN, [&] {
         int r2 = launch_bf16_to_f32(stream, QKV, scratch.as<float>(), (int64_t)M * 3 * d);
         if (r2) return r2;
-        return launch_msa_row_attention_f32(stream, scratch.as<float>(), scores.as<float>(), CTX, ctx_lo.as<bf16_t>(), B, R, C, H,
+        return launch_msa_row_attention_f32(stream, scratch.as<float>(), scores.as<float>(), CTX, 0, B, R, C, H,
                                             3 * d, d, d, 2 * d, row_scale);
       });
       if (rc) return rc;

@@ -49,21 +49,23 @@ int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, co
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,
                     int mask_idx, int token_dropout, int rows_per_msa, float eps);
 int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
-                          int d, float eps, bf16_t* h_lo = nullptr);
+                          int d, float eps, bool split3 = false);   // split3: h rows are [lo | hi | hi], 3 d wide
 int launch_layernorm_f32(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t M, int d,
                          float eps);
 int launch_gather_ln_bf16(hipStream_t s, const float* x, const int32_t* idx, const int32_t* row_map, int P, int width,
                           const float* gamma, const float* beta, bf16_t* h, int64_t n_sel, int d, float eps,
-                          bf16_t* h_lo = nullptr);
-// strict precision mode: fp32 -> (hi, lo) bf16 pair (optionally through erf-GELU); fp32 GELU in place
-int launch_split_bf16(hipStream_t s, const float* src, bf16_t* hi, bf16_t* lo, int64_t n, float scale, bool gelu);
+                          bool split3 = false);
+// strict precision mode: fp32 [rows][K] -> K-concatenated split-bf16 operand bf16 [rows][3K], [lo | hi | hi] for an
+// activation (optionally through erf-GELU), [hi | lo | hi] for a weight; fp32 GELU in place
+int launch_split3_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t rows, int K, float scale, bool gelu, bool weight);
 int launch_gelu_f32(hipStream_t s, float* p, int64_t n);
-// strict precision mode attention: fp32 qkv in, softmax and accumulation in fp32 (VALU), ctx out as a (hi, lo) pair
-int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx_hi, bf16_t* ctx_lo, int64_t n_seq, int T, int H,
+// strict precision mode attention: fp32 qkv in, softmax and accumulation in fp32 (VALU); ctx out as bf16 rows of ld_ctx
+// values, or with split_d = d_model as the [lo | hi | hi] operand rows (ld_ctx = 3 d)
+int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split_d, int64_t n_seq, int T, int H,
                          int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok = nullptr,
                          int pad_idx = -1);
 // strict tied row attention; `scores` is an fp32 scratch of B*H*C*C floats
-int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx_hi, bf16_t* ctx_lo, int B, int R,
+int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx, int split_d, int B, int R,
                                  int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale);
 // d_iter (optional): device-side iteration counter; idx is then the base of a [n_iters][...] table (hipGraph replay)
 int launch_gather_rows(hipStream_t s, const void* src, void* dst, const int32_t* idx, const int32_t* row_map, int P, int width,
