@@ -1,8 +1,17 @@
-// Strict-precision attention (PG_PREC_FP32): the same softmax(q k^T) v per (sequence, head) as attention.hip, but
-// every product and sum is an fp32 VALU op (no bf16 rounding of q, k, v or P), for the 1e-3 logit-parity mode.
-// One 64-lane workgroup = 64 queries of one (sequence, head); a thread owns one query: q[64] and o[64] in
-// registers, K/V tiles of 64 keys staged in LDS as fp32 (all lanes read the same K/V row -> LDS broadcast),
-// online softmax per 64-key tile.  Throughput is irrelevant here (parity mode); correctness and accuracy are.
+// Strict-precision attention (PG_PREC_FP32): the same softmax(q k^T) v per (sequence, head) as attention.hip from
+// fp32 q, k, v, for the 1e-3 logit-parity mode.
+//
+// attention_split_kernel (the default): the MFMA formulation of attention.hip's attention_long_kernel with every
+// operand split into a bf16 (hi, lo) pair in registers -- S = ql.kh + qh.kl + qh.kh and O = vl.ph + vh.pl + vh.ph, fp32
+// accumulation, small terms first -- so q, k, v and P keep ~16 mantissa bits (the dropped lo.lo terms are ~2^-17
+// relative).  One workgroup = (sequence, head, 64 queries); K and V tiles of MAXKB*16 keys are split while they are
+// staged (four LDS tiles: Kh, Kl, Vh, Vl); online softmax across tiles; exp2 on fp32 scores.
+//
+// attention_f32_kernel (PGIBBS_ATTN_F32=valu): the all-VALU fp32 form, kept as an independent cross-check.  One
+// 64-lane workgroup = 64 queries of one (sequence, head); a thread owns one query: q[64] and o[64] in registers, K/V
+// tiles of 64 keys staged in LDS as fp32 (all lanes read the same K/V row -> LDS broadcast), online softmax.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace pg {
@@ -26,6 +35,310 @@ __device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf1
       ((uint2*)(dst + 2 * split_d))[i] = p;
     }
   }
+}
+
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+// 8 fp32 -> 8 bf16 hi (round to nearest even) + 8 bf16 lo = bf16(v - hi)
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+  hi.x = pack_bf16x2(a.x, a.y); hi.y = pack_bf16x2(a.z, a.w); hi.z = pack_bf16x2(b.x, b.y); hi.w = pack_bf16x2(b.z, b.w);
+  lo.x = pack_bf16x2(a.x - __uint_as_float(hi.x << 16), a.y - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack_bf16x2(a.z - __uint_as_float(hi.y << 16), a.w - __uint_as_float(hi.y & 0xffff0000u));
+  lo.z = pack_bf16x2(b.x - __uint_as_float(hi.z << 16), b.y - __uint_as_float(hi.z & 0xffff0000u));
+  lo.w = pack_bf16x2(b.z - __uint_as_float(hi.w << 16), b.w - __uint_as_float(hi.w & 0xffff0000u));
+}
+
+// Building blocks shared by the three split-bf16 MFMA kernels (full attention, tied-row scores, tied-row apply).
+// Fragment geometry as in attention.hip: fr = lane & 15 is the wave's query (MFMA column), fq = lane >> 4; a score
+// block st[kb][r] = S[query fr][key kb*16 + fq*4 + r]; O^T blocks o[db][r] = O[query fr][d = db*16 + fq*4 + r].
+template <int MAXKB>
+struct SplitAttn {
+  static constexpr int tpad = MAXKB * 16, nkc = MAXKB / 2;
+  static_assert(MAXKB % 2 == 0, "two 16-key blocks per 32-wide PV step");
+  static constexpr float LOG2E = 1.44269504088896341f;
+
+  // rows 0 .. tpad-1 of 64 fp32 at src + row*ld (rows >= n_valid read as zero) -> (hi, lo) bf16 tiles; a tile row is
+  // 128 B with its 16-B chunks XOR-swizzled: row*128 + ((c ^ (row & 7)) << 4).  All global loads in flight first.
+  static __device__ __forceinline__ void stage(const float* __restrict__ src, size_t ld, int n_valid, char* Xh, char* Xl, int tid) {
+    constexpr int NIT = (tpad * 8 + 255) / 256;      // one item = 8 d of one key
+    float4 r0[NIT], r1[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256, row = i >> 3, c = i & 7;
+      r0[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      r1[it] = r0[it];
+      if (i < tpad * 8 && row < n_valid) {
+        const float4* p = (const float4*)(src + (size_t)row * ld + c * 8);
+        r0[it] = p[0];
+        r1[it] = p[1];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256, row = i >> 3, c = i & 7;
+      if (i < tpad * 8) {
+        uint4 hi, lo;
+        split8(r0[it], r1[it], hi, lo);
+        const int a = row * 128 + ((c ^ (row & 7)) << 4);
+        *(uint4*)(Xh + a) = hi;
+        *(uint4*)(Xl + a) = lo;
+      }
+    }
+  }
+
+  // Q fragments (MFMA B operand) of the query whose 64 fp32 start at qrow: d = kk*32 + fq*8 .. +7
+  static __device__ __forceinline__ void load_q(const float* __restrict__ qrow, int fq, bf16x8 (&qh)[2], bf16x8 (&ql)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float4* p = (const float4*)(qrow + kk * 32 + fq * 8);
+      uint4 hi, lo;
+      split8(p[0], p[1], hi, lo);
+      qh[kk] = __builtin_bit_cast(bf16x8, hi);
+      ql[kk] = __builtin_bit_cast(bf16x8, lo);
+    }
+  }
+
+  // st[kb] += (K tile rows kb*16 .. +15) . q :  kl.qh + kh.ql + kh.qh
+  static __device__ __forceinline__ void qk(const char* Kh, const char* Kl, const bf16x8 (&qh)[2], const bf16x8 (&ql)[2],
+                                            f32x4 (&st)[MAXKB], int fr, int fq) {
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+      f32x4 a = st[kb];
+      const int krow = kb * 16 + fr;
+      bf16x8 kh[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ad = krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4);
+        kh[kk] = *(const bf16x8*)(Kh + ad);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Kl + ad), qh[kk], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kk], ql[kk], a, 0, 0, 0);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kk], qh[kk], a, 0, 0, 0);
+      st[kb] = a;
+    }
+  }
+
+  // One online-softmax step over the tile's scores st (masked entries hold -3e38), then O += V^T P^T with P and V split.
+  // K-slot (fq*8 + j) of 32-key chunk c <-> key (2c + (j>>2))*16 + fq*4 + (j&3): exactly the order the lane holds P in.
+  static __device__ __forceinline__ void softmax_pv(f32x4 (&st)[MAXKB], f32x4 (&o)[4], float& m, float& l, const char* Vh,
+                                                    const char* Vl, int fr, int fq) {
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[kb][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float mn = fmaxf(m, tmax);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+    const float mneg = -mn * LOG2E;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = st[kb][r] > -1.0e38f ? __builtin_amdgcn_exp2f(fmaf(st[kb][r], LOG2E, mneg)) : 0.f;
+        st[kb][r] = e;
+        psum += e;
+      }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    l = l * alpha + psum;
+    m = mn;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+    }
+#pragma unroll
+    for (int c = 0; c < nkc; ++c) {
+      const f32x4 p0 = st[2 * c], p1 = st[2 * c + 1];
+      uint4 ph, pl;
+      split8(make_float4(p0[0], p0[1], p0[2], p0[3]), make_float4(p1[0], p1[1], p1[2], p1[3]), ph, pl);
+      const bf16x8 pfh = __builtin_bit_cast(bf16x8, ph), pfl = __builtin_bit_cast(bf16x8, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        union { bf16x8 v; uint2 h2[2]; } vh, vl;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {           // transposed LDS read (attention.hip): lane fr gets V[key0..key0+3][d = db*16 + fr]
+          const int krow = (2 * c + hh) * 16 + fq * 4 + (fr >> 2);
+          const int dcol = db * 16 + (fr & 3) * 4;
+          const int ad = krow * 128 + (((dcol >> 3) ^ (krow & 7)) << 4) + ((dcol >> 2) & 1) * 8;
+          vh.h2[hh] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
+                                                    (__attribute__((address_space(3))) char*)(Vh + ad))));
+          vl.h2[hh] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
+                                                    (__attribute__((address_space(3))) char*)(Vl + ad))));
+        }
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl.v, pfh, o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, pfl, o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, pfh, o[db], 0, 0, 0);
+      }
+    }
+  }
+
+  // dst = the query's context row at column h*64 + fq*4; bf16, or the strict mode's [lo | hi | hi] operand row
+  static __device__ __forceinline__ void store_ctx(const f32x4 (&o)[4], float l, bf16_t* dst, int split_d) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const float a = o[db][0] * inv, b = o[db][1] * inv, c = o[db][2] * inv, d = o[db][3] * inv;
+      uint2 p, r;
+      p.x = pack_bf16x2(a, b);
+      p.y = pack_bf16x2(c, d);
+      if (!split_d) {
+        *(uint2*)(dst + db * 16) = p;
+      } else {
+        r.x = pack_bf16x2(a - __uint_as_float(p.x << 16), b - __uint_as_float(p.x & 0xffff0000u));
+        r.y = pack_bf16x2(c - __uint_as_float(p.y << 16), d - __uint_as_float(p.y & 0xffff0000u));
+        *(uint2*)(dst + db * 16) = r;
+        *(uint2*)(dst + split_d + db * 16) = p;
+        *(uint2*)(dst + 2 * split_d + db * 16) = p;
+      }
+    }
+  }
+};
+
+// ---- full attention: one workgroup = (sequence, head, 64 queries), wave w owns queries q0 .. q0+15 -----------------
+template <int MAXKB>
+__global__ __launch_bounds__(256, 2) void attention_split_kernel(
+    const float* __restrict__ qkv, bf16_t* __restrict__ ctx, int split_d, int T, int H, int ld_qkv_, int ld_ctx_, int k_off,
+    int v_off, SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok, int pad_idx) {
+  using A = SplitAttn<MAXKB>;
+  constexpr int tpad = A::tpad;
+  __shared__ __attribute__((aligned(16))) char smem[4 * tpad * 128];
+  char *Kh = smem, *Kl = smem + tpad * 128, *Vh = smem + 2 * tpad * 128, *Vl = smem + 3 * tpad * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qc = blockIdx.x % n_qchunk, sh = blockIdx.x / n_qchunk;
+  const int seq = sh / H, h = sh % H;
+  const size_t row0 = (size_t)(seq / sl.inner_count) * sl.outer_rows + (size_t)(seq % sl.inner_count) * sl.inner_rows;
+  const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
+  const float* base = qkv + row0 * ld_qkv_ + h * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int q0 = qc * 64 + wave * 16;
+  const bool active = q0 < T;                        // wave-uniform
+  bf16x8 qh[2], ql[2];
+  A::load_q(base + (size_t)(q0 + fr < T ? q0 + fr : T - 1) * ld_qkv, fq, qh, ql);
+  f32x4 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, l = 0.f;
+
+  for (int k0 = 0; k0 < T; k0 += tpad) {
+    __syncthreads();
+    A::stage(base + (size_t)k0 * ld_qkv + k_off, ld_qkv, T - k0, Kh, Kl, tid);
+    A::stage(base + (size_t)k0 * ld_qkv + v_off, ld_qkv, T - k0, Vh, Vl, tid);
+    __syncthreads();
+    if (!active) continue;
+    f32x4 st[MAXKB];
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    A::qk(Kh, Kl, qh, ql, st, fr, fq);
+    const int tl = T - k0 - fq * 4;              // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
+    if (key_tok) {                               // <pad> keys of a ragged batch (key_tok = token buffer, sequence seq at seq*T)
+      const int32_t* kt = key_tok + (size_t)seq * T + k0;
+#pragma unroll
+      for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * 16 + fq * 4 + r;
+          if (k0 + key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
+        }
+    }
+    A::softmax_pv(st, o, m, l, Vh, Vl, fr, fq);
+  }
+  const int q = q0 + fr;
+  if (active && q < T) A::store_ctx(o, l, ctx + row0 * ld_ctx_ + (size_t)q * ld_ctx + h * 64 + fq * 4, split_d);
+}
+
+// ---- tied row attention (MSA), step 1: S[b,h][i][j] = scale * sum_r q_r[i] . k_r[j] ---------------------------------
+// One workgroup = (msa b, head h, 64 queries, one key tile); the score blocks stay in the MFMA accumulators while the
+// R alignment rows stream through the K tile.  S rows are ldS floats (C rounded up to 4) for 16-byte accesses.
+template <int MAXKB>
+__global__ __launch_bounds__(256, 2) void msa_row_scores_split_kernel(const float* __restrict__ qkv, float* __restrict__ S, int R,
+                                                                      int C, int H, int ld_qkv, int k_off, float scale,
+                                                                      int n_qchunk, int n_ktile, int ldS) {
+  using A = SplitAttn<MAXKB>;
+  constexpr int tpad = A::tpad;
+  __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128];
+  char *Kh = smem, *Kl = smem + tpad * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kt = blockIdx.x % n_ktile, qc = (blockIdx.x / n_ktile) % n_qchunk, bh = blockIdx.x / (n_ktile * n_qchunk);
+  const int b = bh / H, h = bh % H;
+  const float* base = qkv + (size_t)b * R * C * ld_qkv + h * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int q0 = qc * 64 + wave * 16, k0 = kt * tpad;
+  const bool active = q0 < C;
+  const int qrow = q0 + fr < C ? q0 + fr : C - 1;
+  f32x4 st[MAXKB];
+#pragma unroll
+  for (int kb = 0; kb < MAXKB; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < R; ++r) {
+    const float* rb = base + (size_t)r * C * ld_qkv;
+    bf16x8 qh[2], ql[2];
+    A::load_q(rb + (size_t)qrow * ld_qkv, fq, qh, ql);
+    __syncthreads();
+    A::stage(rb + (size_t)k0 * ld_qkv + k_off, ld_qkv, C - k0, Kh, Kl, tid);
+    __syncthreads();
+    if (active) A::qk(Kh, Kl, qh, ql, st, fr, fq);
+  }
+  const int q = q0 + fr;
+  if (active && q < C) {
+    float* dst = S + ((size_t)bh * C + q) * ldS + k0 + fq * 4;
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb)
+      if (k0 + kb * 16 + fq * 4 < ldS)
+        *(float4*)(dst + kb * 16) = make_float4(st[kb][0] * scale, st[kb][1] * scale, st[kb][2] * scale, st[kb][3] * scale);
+  }
+}
+
+// ---- tied row attention, step 2: ctx_r = softmax_j(S) v_r; one workgroup = (b, h, alignment row r, 64 queries) ---------
+template <int MAXKB>
+__global__ __launch_bounds__(256, 2) void msa_row_apply_split_kernel(const float* __restrict__ qkv, const float* __restrict__ S,
+                                                                     bf16_t* __restrict__ ctx, int split_d, int R, int C, int H,
+                                                                     int ld_qkv, int ld_ctx, int v_off, int n_qchunk, int ldS) {
+  using A = SplitAttn<MAXKB>;
+  constexpr int tpad = A::tpad;
+  __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128];
+  char *Vh = smem, *Vl = smem + tpad * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qc = blockIdx.x % n_qchunk, r = (blockIdx.x / n_qchunk) % R, bh = blockIdx.x / (n_qchunk * R);
+  const int b = bh / H, h = bh % H;
+  const float* rb = qkv + ((size_t)b * R + r) * C * ld_qkv + h * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int q0 = qc * 64 + wave * 16;
+  const bool active = q0 < C;
+  const int q = q0 + fr;
+  const float* srow = S + ((size_t)bh * C + (q < C ? q : C - 1)) * ldS + fq * 4;
+  f32x4 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -3.0e38f, l = 0.f;
+  for (int k0 = 0; k0 < C; k0 += tpad) {
+    f32x4 st[MAXKB];
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb) {
+      const int key0 = k0 + kb * 16 + fq * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (key0 < ldS) v = *(const float4*)(srow + k0 + kb * 16);
+      st[kb][0] = key0 < C ? v.x : -3.0e38f;
+      st[kb][1] = key0 + 1 < C ? v.y : -3.0e38f;
+      st[kb][2] = key0 + 2 < C ? v.z : -3.0e38f;
+      st[kb][3] = key0 + 3 < C ? v.w : -3.0e38f;
+    }
+    __syncthreads();
+    A::stage(rb + (size_t)k0 * ld_qkv + v_off, ld_qkv, C - k0, Vh, Vl, tid);
+    __syncthreads();
+    if (active) A::softmax_pv(st, o, m, l, Vh, Vl, fr, fq);
+  }
+  if (active && q < C) A::store_ctx(o, l, ctx + (((size_t)b * R + r) * C + q) * ld_ctx + h * 64 + fq * 4, split_d);
 }
 
 __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ ctx,
@@ -113,7 +426,7 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
 // ---- strict tied row attention (MSA): S = scale * sum_r q_r k_r^T (fp32, to a scratch buffer), then
 //      ctx[r] = softmax_j(S) v_r with the row statistics recomputed per thread ------------------------------
 __global__ __launch_bounds__(64) void msa_row_scores_f32_kernel(const float* __restrict__ qkv, float* __restrict__ S, int R,
-                                                               int C, int H, int ld_qkv, int k_off, float scale, int n_chunk) {
+                                                               int C, int H, int ld_qkv, int k_off, float scale, int n_chunk, int ldS) {
   __shared__ __attribute__((aligned(16))) float Ks[64 * 64];
   const int lane = threadIdx.x;
   const int jc = blockIdx.x % n_chunk, ic = (blockIdx.x / n_chunk) % n_chunk, bh = blockIdx.x / (n_chunk * n_chunk);
@@ -156,7 +469,7 @@ __global__ __launch_bounds__(64) void msa_row_scores_f32_kernel(const float* __r
     }
   }
   if (qi < C) {
-    float* dst = S + ((size_t)bh * C + qi) * C + jc * 64;
+    float* dst = S + ((size_t)bh * C + qi) * ldS + jc * 64;
 #pragma unroll
     for (int key = 0; key < 64; ++key)
       if (key < nk) dst[key] = s[key] * scale;
@@ -165,7 +478,7 @@ __global__ __launch_bounds__(64) void msa_row_scores_f32_kernel(const float* __r
 
 __global__ __launch_bounds__(64) void msa_row_apply_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ S,
                                                               bf16_t* __restrict__ ctx, int split_d, int R,
-                                                              int C, int H, int ld_qkv, int ld_ctx, int v_off, int n_chunk) {
+                                                              int C, int H, int ld_qkv, int ld_ctx, int v_off, int n_chunk, int ldS) {
   __shared__ __attribute__((aligned(16))) float Vs[64 * 64];
   const int lane = threadIdx.x;
   const int ic = blockIdx.x % n_chunk, r = (blockIdx.x / n_chunk) % R, bh = blockIdx.x / (n_chunk * R);
@@ -173,7 +486,7 @@ __global__ __launch_bounds__(64) void msa_row_apply_f32_kernel(const float* __re
   const float* rb = qkv + ((size_t)b * R + r) * C * ld_qkv + h * 64;
   const int qi = ic * 64 + lane;
   const bool valid = qi < C;
-  const float* srow = S + ((size_t)bh * C + (valid ? qi : C - 1)) * C;
+  const float* srow = S + ((size_t)bh * C + (valid ? qi : C - 1)) * ldS;
   float m = -3.0e38f;
   for (int j = 0; j < C; ++j) m = fmaxf(m, srow[j]);
   float l = 0.f;
@@ -206,14 +519,35 @@ __global__ __launch_bounds__(64) void msa_row_apply_f32_kernel(const float* __re
   if (valid) store_ctx64(o, 1.0f / l, ctx + (((size_t)b * R + r) * C + qi) * ld_ctx + h * 64, split_d);
 }
 
+static int attn_f32_mode() {
+  static const int mode = [] { const char* e = getenv("PGIBBS_ATTN_F32"); return !e ? 0 : (e[0] == 'v' ? -1 : atoi(e)); }();
+  return mode;
+}
+
 int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx, int split_d, int B, int R,
                                  int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale) {
   if (B == 0 || R == 0) return 0;
   const int n_chunk = (C + 63) / 64;
-  hipLaunchKernelGGL(msa_row_scores_f32_kernel, dim3((unsigned)(B * H * n_chunk * n_chunk)), dim3(64), 0, s, qkv, scores, R, C, H,
-                     ld_qkv, k_off, scale, n_chunk);
-  hipLaunchKernelGGL(msa_row_apply_f32_kernel, dim3((unsigned)(B * H * R * n_chunk)), dim3(64), 0, s, qkv, scores, ctx, split_d,
-                     R, C, H, ld_qkv, ld_ctx, v_off, n_chunk);
+  const int ldS = msa_row_scores_ld(C);         // `scores` holds B*H*C rows of ldS floats
+  if (attn_f32_mode() < 0) {
+    hipLaunchKernelGGL(msa_row_scores_f32_kernel, dim3((unsigned)(B * H * n_chunk * n_chunk)), dim3(64), 0, s, qkv, scores, R, C, H,
+                       ld_qkv, k_off, scale, n_chunk, ldS);
+    hipLaunchKernelGGL(msa_row_apply_f32_kernel, dim3((unsigned)(B * H * R * n_chunk)), dim3(64), 0, s, qkv, scores, ctx, split_d,
+                       R, C, H, ld_qkv, ld_ctx, v_off, n_chunk, ldS);
+  } else {
+    if (C <= 64) {
+      hipLaunchKernelGGL(msa_row_scores_split_kernel<4>, dim3((unsigned)(B * H * n_chunk)), dim3(256), 0, s, qkv, scores, R, C, H,
+                         ld_qkv, k_off, scale, n_chunk, 1, ldS);
+      hipLaunchKernelGGL(msa_row_apply_split_kernel<4>, dim3((unsigned)(B * H * R * n_chunk)), dim3(256), 0, s, qkv, scores, ctx,
+                         split_d, R, C, H, ld_qkv, ld_ctx, v_off, n_chunk, ldS);
+    } else {
+      const int n_ktile = (C + 159) / 160;
+      hipLaunchKernelGGL(msa_row_scores_split_kernel<10>, dim3((unsigned)(B * H * n_chunk * n_ktile)), dim3(256), 0, s, qkv, scores,
+                         R, C, H, ld_qkv, k_off, scale, n_chunk, n_ktile, ldS);
+      hipLaunchKernelGGL(msa_row_apply_split_kernel<10>, dim3((unsigned)(B * H * R * n_chunk)), dim3(256), 0, s, qkv, scores, ctx,
+                         split_d, R, C, H, ld_qkv, ld_ctx, v_off, n_chunk, ldS);
+    }
+  }
   PG_HIP(hipGetLastError());
   return 0;
 }
@@ -224,8 +558,22 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
   if (T <= 0) return fail(1, "attention: empty sequence");
   const int n_qchunk = (T + 63) / 64;
   if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
-  hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), dim3(64), 0, s, qkv, ctx, split_d, T, H,
-                     ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx);
+  const int mode = attn_f32_mode();
+  const dim3 grid((unsigned)(n_seq * H * n_qchunk));
+  if (mode < 0) {
+    hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(64), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl,
+                       n_qchunk, key_tok, pad_idx);
+  } else {
+    // key tile: 64 keys for short sequences, else 160 (80 KB of LDS: two workgroups per CU; at T = 258 a single 288-key
+    // tile with one workgroup per CU was 1.6x slower)
+    const int kb = T <= 64 ? 4 : 10;
+#define PG_ATT_SPLIT(KB)                                                                                                  \
+  hipLaunchKernelGGL(attention_split_kernel<KB>, grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
+                     n_qchunk, key_tok, pad_idx)
+    if (kb <= 4) PG_ATT_SPLIT(4);
+    else PG_ATT_SPLIT(10);
+#undef PG_ATT_SPLIT
+  }
   PG_HIP(hipGetLastError());
   return 0;
 }

@@ -455,7 +455,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     if ((rc = h.ensure((size_t)Mp * 3 * d * 2, stream)) || (rc = ctx.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;   // [lo | hi | hi] rows
     if ((rc = qkv.ensure((size_t)Mp * 3 * d * 4, stream))) return rc;
     if ((rc = ffn.ensure((size_t)Mp * 3 * f * 2, stream)) || (rc = ffn_f32.ensure((size_t)Mp * f * 4, stream))) return rc;
-    if ((rc = scores.ensure((size_t)B * H * C * C * 4, stream))) return rc;
+    if ((rc = scores.ensure((size_t)B * H * C * msa_row_scores_ld(C) * 4, stream))) return rc;
     float* Xs = x.as<float>();
     float* QKVf = qkv.as<float>();
     bf16_t *H3 = h.as<bf16_t>(), *C3 = ctx.as<bf16_t>();
@@ -505,7 +505,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0); }))) return rc;
     } else {
       // alignments wider than the MFMA row-attention kernel's register budget: fp32 scores through a scratch buffer
-      if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * C * 4, stream))) return rc;
+      if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * msa_row_scores_ld(C) * 4, stream))) return rc;
       rc = timed(PC_ATTN, [&] {
         int r2 = launch_bf16_to_f32(stream, QKV, scratch.as<float>(), (int64_t)M * 3 * d);
         if (r2) return r2;

@@ -64,7 +64,8 @@ int launch_gelu_f32(hipStream_t s, float* p, int64_t n);
 int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split_d, int64_t n_seq, int T, int H,
                          int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok = nullptr,
                          int pad_idx = -1);
-// strict tied row attention; `scores` is an fp32 scratch of B*H*C*C floats
+// strict tied row attention; `scores` is an fp32 scratch of B*H*C rows of msa_row_scores_ld(C) floats
+static inline int msa_row_scores_ld(int C) { return (C + 3) & ~3; }
 int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx, int split_d, int B, int R,
                                  int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale);
 // d_iter (optional): device-side iteration counter; idx is then the base of a [n_iters][...] table (hipGraph replay)
