@@ -196,7 +196,8 @@ int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t*
 
 /* ---- kernel-level debug entry points (parity tests call individual kernels through these) --- */
 /* out[M][N] = x[M][K] @ w[N][K]^T + bias (fp32 host buffers; computed in `precision`); epi: 0 none, 1 gelu,
- * 2 residual (out is read too: out += x w^T + bias), 3 bf16 output, 4 bf16 output + gelu */
+ * 2 residual (out is read too: out += x w^T + bias), 3 bf16 output, 4 bf16 output + gelu.  PG_PREC_FP32 (the engine's
+ * strict-mode projection: one GEMM over K-concatenated split-bf16 operands) takes epi 0 and 2 */
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi);
 /* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events; M a multiple of 16,
@@ -206,11 +207,12 @@ int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int
 /* y = LayerNorm(x[M][d]) * gamma + beta */
 int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                      float eps);
-/* softmax(q k^T) v per (b, h); q already scaled; qkv[B][T][3*H*64] fp32 -> ctx[B][T][H*64] */
+/* softmax(q k^T) v per (b, h); q already scaled; qkv[B][T][3*H*64] fp32 -> ctx[B][T][H*64]; PG_PREC_BF16 or PG_PREC_FP32
+ * (split-bf16 MFMA kernel, output = hi + lo of the operand rows it writes) */
 int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, int B, int T, int H);
 
 /* MSA attention blocks: qkv[B][R][C][3*H*64] fp32 -> ctx[B][R][C][H*64]; which = 0 tied row attention (scores * scale),
- * 1 column attention (q pre-scaled) */
+ * 1 column attention (q pre-scaled); 2 / 3 = the same two with the strict precision mode's kernels */
 int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, int B, int R, int C, int H, float scale);
 
 #ifdef __cplusplus

@@ -390,27 +390,52 @@ int dbg_device(int device) {
   PG_HIP(hipSetDevice(device));
   return PG_OK;
 }
+// device rows [lo | hi | hi] (3 d bf16, the strict mode's activation operand) -> host fp32 rows hi + lo; also checks that
+// the two hi copies agree
+int split3_rows_to_host(const bf16_t* c3, float* dst, int64_t M, int d) {
+  PG_HIP(hipDeviceSynchronize());
+  std::vector<bf16_t> h((size_t)M * 3 * d);
+  PG_HIP(hipMemcpy(h.data(), c3, h.size() * 2, hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < M; ++r)
+    for (int c = 0; c < d; ++c) {
+      const bf16_t lo = h[(size_t)r * 3 * d + c], hi = h[(size_t)r * 3 * d + d + c], hi2 = h[(size_t)r * 3 * d + 2 * d + c];
+      if (hi != hi2) return fail(PG_ERR_HIP, "split operand row: the two hi copies differ");
+      dst[(size_t)r * d + c] = bf16_to_f32(hi) + bf16_to_f32(lo);
+    }
+  return PG_OK;
+}
 }  // namespace
 
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi) {
-  if (precision != PG_PREC_BF16) return fail(PG_ERR_UNSUPPORTED, "only bf16");
+  if (precision != PG_PREC_BF16 && precision != PG_PREC_FP32) return fail(PG_ERR_INVALID, "unknown precision mode");
   if (!x || !w || !bias || !out || M < 1 || N % 64 || K % 64) return fail(PG_ERR_INVALID, "pg_dbg_gemm: bad argument");
   DeviceGuard g(-1);
   int rc = dbg_device(device);
   if (rc) return rc;
   const int Mp = round_up(M, kRowPad);
+  const int ks = precision == PG_PREC_FP32 ? 3 : 1;      // strict mode: K-concatenated split-bf16 operands (engine.h dense3)
   Tmp t;
   float* dx = (float*)t.get((size_t)Mp * K * 4);
   float* dw = (float*)t.get((size_t)N * K * 4);
   float* db = (float*)t.get((size_t)N * 4);
   float* dout = (float*)t.get((size_t)Mp * N * 4);
-  bf16_t* bx = (bf16_t*)t.get((size_t)Mp * K * 2);
-  bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2);
+  bf16_t* bx = (bf16_t*)t.get((size_t)Mp * K * 2 * ks);
+  bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2 * ks);
   if (!dx || !dw || !db || !dout || !bx || !bw) return fail(PG_ERR_HIP, "hipMalloc failed");
   PG_HIP(hipMemcpy(dx, x, (size_t)M * K * 4, hipMemcpyHostToDevice));
   PG_HIP(hipMemcpy(dw, w, (size_t)N * K * 4, hipMemcpyHostToDevice));
   PG_HIP(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+  if (precision == PG_PREC_FP32) {
+    if (epi != 0 && epi != 2) return fail(PG_ERR_UNSUPPORTED, "strict mode: plain (0) and residual (2) epilogues only");
+    if ((rc = launch_split3_bf16(nullptr, dx, bx, Mp, K, 1.f, false, false))) return rc;
+    if ((rc = launch_split3_bf16(nullptr, dw, bw, N, K, 1.f, false, true))) return rc;
+    if (epi == 2) PG_HIP(hipMemcpy(dout, out, (size_t)M * N * 4, hipMemcpyHostToDevice));
+    if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, Mp, N, 3 * K, 3 * K, 3 * K, N, epi == 2 ? EPI_F32_RESID : EPI_F32))) return rc;
+    PG_HIP(hipDeviceSynchronize());
+    PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    return PG_OK;
+  }
   if ((rc = launch_f32_to_bf16(nullptr, dx, bx, (int64_t)Mp * K, 1.f))) return rc;
   if ((rc = launch_f32_to_bf16(nullptr, dw, bw, (int64_t)N * K, 1.f))) return rc;
   if (epi == 2) PG_HIP(hipMemcpy(dout, out, (size_t)M * N * 4, hipMemcpyHostToDevice));     // residual variant: out += x w^T + b
@@ -491,7 +516,7 @@ int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float
 }
 
 int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, int B, int T, int H) {
-  if (precision != PG_PREC_BF16) return fail(PG_ERR_UNSUPPORTED, "only bf16");
+  if (precision != PG_PREC_BF16 && precision != PG_PREC_FP32) return fail(PG_ERR_INVALID, "unknown precision mode");
   if (!qkv || !ctx || B < 1 || T < 1 || H < 1) return fail(PG_ERR_INVALID, "pg_dbg_attention: bad argument");
   DeviceGuard g(-1);
   int rc = dbg_device(device);
@@ -500,6 +525,14 @@ int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, in
   const int64_t M = (int64_t)B * T;
   Tmp t;
   float* dq = (float*)t.get((size_t)M * 3 * d * 4);
+  if (precision == PG_PREC_FP32) {
+    bf16_t* c3 = (bf16_t*)t.get((size_t)M * 3 * d * 2);
+    if (!dq || !c3) return fail(PG_ERR_HIP, "hipMalloc failed");
+    PG_HIP(hipMemcpy(dq, qkv, (size_t)M * 3 * d * 4, hipMemcpyHostToDevice));
+    const SeqLayout chain = {1, T, 0, 1};
+    if ((rc = launch_attention_f32(nullptr, dq, c3, d, B, T, H, 3 * d, 3 * d, d, 2 * d, chain))) return rc;
+    return split3_rows_to_host(c3, ctx, M, d);
+  }
   bf16_t* bq = (bf16_t*)t.get((size_t)M * 3 * d * 2);
   bf16_t* bc = (bf16_t*)t.get((size_t)M * d * 2);
   float* dc = (float*)t.get((size_t)M * d * 4);
@@ -514,7 +547,7 @@ int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, in
 }
 
 /* MSA attention blocks on fp32 host buffers qkv[B][R][C][3*H*64] -> ctx[B][R][C][H*64]; which: 0 = tied row attention
- * (scores scaled by `scale`), 1 = column attention (q already scaled) */
+ * (scores scaled by `scale`), 1 = column attention (q already scaled); 2 / 3 = the same two in the strict precision mode */
 int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, int B, int R, int C, int H, float scale) {
   if (!qkv || !ctx || B < 1 || R < 1 || C < 1 || H < 1) return fail(PG_ERR_INVALID, "pg_dbg_msa_attention: bad argument");
   DeviceGuard g(-1);
@@ -524,6 +557,17 @@ int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, in
   const int64_t M = (int64_t)B * R * C;
   Tmp t;
   float* dq = (float*)t.get((size_t)M * 3 * d * 4);
+  if (which == 2 || which == 3) {      // strict precision mode kernels: fp32 in, [lo | hi | hi] operand rows out
+    bf16_t* c3 = (bf16_t*)t.get((size_t)M * 3 * d * 2);
+    float* sc = which == 2 ? (float*)t.get((size_t)B * H * C * msa_row_scores_ld(C) * 4) : nullptr;
+    if (!dq || !c3 || (which == 2 && !sc)) return fail(PG_ERR_HIP, "hipMalloc failed");
+    PG_HIP(hipMemcpy(dq, qkv, (size_t)M * 3 * d * 4, hipMemcpyHostToDevice));
+    const SeqLayout col = {C, R * C, 1, C};
+    if (which == 2) rc = launch_msa_row_attention_f32(nullptr, dq, sc, c3, d, B, R, C, H, 3 * d, 3 * d, d, 2 * d, scale);
+    else rc = launch_attention_f32(nullptr, dq, c3, d, (int64_t)B * C, R, H, 3 * d, 3 * d, d, 2 * d, col);
+    if (rc) return rc;
+    return split3_rows_to_host(c3, ctx, M, d);
+  }
   bf16_t* bq = (bf16_t*)t.get((size_t)M * 3 * d * 2);
   bf16_t* bc = (bf16_t*)t.get((size_t)M * d * 2);
   float* dc = (float*)t.get((size_t)M * d * 4);

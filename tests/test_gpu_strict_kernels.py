@@ -1,0 +1,124 @@
+"""Kernel-level parity of the strict precision mode (PG_PREC_FP32, the mode that meets north_star's 1e-3 logit tolerance) against
+float64 numpy on the UNROUNDED fp32 inputs -- no bf16 rounding is granted to the kernels here:
+
+  * the projection: one bf16 MFMA GEMM over the K-concatenated split operands [xl | xh | xh] . [wh | wl | wh]^T (engine.h dense3),
+  * attention: q, k, v and P split into bf16 (hi, lo) pairs, three MFMAs per product (csrc/attention_f32.hip) -- whole-sequence,
+    multi-tile (online softmax), tied-row scores + apply, column layout,
+  * the all-VALU fp32 attention kernels (PGIBBS_ATTN_F32=valu, read once per process -> child process) as an independent
+    second implementation: both must agree with numpy to the same bound.
+
+Outputs come back as hi + lo of the operand rows the kernels write (16 mantissa bits), so the bound is ~2^-16 relative.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from protein_gibbs_sampler_amd import _lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REL = 6e-5          # (hi, lo) bf16 pair = 16-17 mantissa bits on every operand; fp32 accumulation
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(513, 1280, 1280, 0), (300, 384, 256, 2), (40, 256, 64, 0), (256, 128, 192, 2),
+                                       (2048, 2304, 128, 0), (8192 + 256, 1280, 320, 2), (1000, 768, 3072, 0)])
+def test_strict_projection_gemm(M, N, K, epi):
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
+    b = rng.standard_normal(N, dtype=np.float32)
+    out = rng.standard_normal((M, N), dtype=np.float32) * 3
+    res0 = out.astype(np.float64)
+    _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_FP32, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if epi == 2:
+        ref = ref + res0
+    err = np.abs(out - ref).max()
+    # bf16 operands alone would sit at ~4e-3 here
+    assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
+def _attention_ref(qkv, d, H):
+    B, T = qkv.shape[:2]
+    r = qkv.astype(np.float64)
+    q, k, v = (r[..., i * d:(i + 1) * d].reshape(B, T, H, 64).transpose(0, 2, 1, 3) for i in range(3))
+    a = q @ k.transpose(0, 1, 3, 2)
+    p = np.exp(a - a.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    return (p @ v).transpose(0, 2, 1, 3).reshape(B, T, d)
+
+
+ATT_CASES = [(2, 27, 2), (3, 258, 2), (1, 16, 1), (2, 64, 1), (1, 65, 1), (2, 100, 3), (1, 160, 1), (1, 161, 2), (1, 513, 1), (1, 1024, 1)]
+
+
+@pytest.mark.parametrize("B,T,H", ATT_CASES)
+def test_strict_attention(B, T, H):
+    rng = np.random.default_rng(T)
+    d = H * 64
+    qkv = rng.standard_normal((B, T, 3 * d), dtype=np.float32)
+    qkv[..., :d] *= 0.35                                       # q is pre-scaled in the engine
+    ctx = np.empty((B, T, d), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_attention(0, _lib.PG_PREC_FP32, _lib.ptr(qkv), _lib.ptr(ctx), B, T, H))
+    ref = _attention_ref(qkv, d, H)
+    err = np.abs(ctx - ref).max()
+    assert err < REL * max(1.0, np.abs(ref).max()), err       # the bf16 kernel is held to 2.5e-2 on the same inputs
+
+
+MSA_CASES = [(2, 3, 20, 2), (1, 32, 257, 2), (2, 5, 70, 1), (1, 8, 130, 3), (1, 4, 64, 2), (1, 2, 300, 1), (1, 16, 513, 1), (3, 9, 65, 2)]
+
+
+def _msa_refs(qkv, B, R, C, H, scale):
+    d = H * 64
+    r = qkv.astype(np.float64)
+    q, k, v = (r[..., i * d:(i + 1) * d].reshape(B, R, C, H, 64) for i in range(3))
+    a = np.einsum("brihd,brjhd->bhij", q, k) * float(scale)
+    p = np.exp(a - a.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    row = np.einsum("bhij,brjhd->brihd", p, v).reshape(B, R, C, d)
+    a = np.einsum("bichd,bjchd->bhcij", q, k)
+    p = np.exp(a - a.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    col = np.einsum("bhcij,bjchd->bichd", p, v).reshape(B, R, C, d)
+    return row, col
+
+
+@pytest.mark.parametrize("B,R,C,H", MSA_CASES)
+def test_strict_msa_attention(B, R, C, H):
+    rng = np.random.default_rng(C + R)
+    d = H * 64
+    qkv = rng.standard_normal((B, R, C, 3 * d), dtype=np.float32)
+    qkv[..., :d] *= 0.35
+    scale = np.float32(1.0 / np.sqrt(R))
+    row_ref, col_ref = _msa_refs(qkv, B, R, C, H, scale)
+    for which, ref in ((2, row_ref), (3, col_ref)):
+        ctx = np.empty((B, R, C, d), dtype=np.float32)
+        _lib.check(_lib.lib().pg_dbg_msa_attention(0, which, _lib.ptr(qkv), _lib.ptr(ctx), B, R, C, H, float(scale)))
+        err = np.abs(ctx - ref).max()
+        assert err < REL * max(1.0, np.abs(ref).max()), (which, err)
+
+
+_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import test_gpu_strict_kernels as t
+for c in t.ATT_CASES[:6]:
+    t.test_strict_attention(*c)
+for c in t.MSA_CASES[:5]:
+    t.test_strict_msa_attention(*c)
+print("valu kernels OK")
+"""
+
+
+def test_valu_attention_kernels_agree_too():
+    """PGIBBS_ATTN_F32=valu selects the all-VALU fp32 kernels: an independent formulation (no MFMA, no operand split, thread per
+    query) that must meet the same bound against numpy -- a cross-check that the bound above is not an artefact of the split."""
+    env = dict(os.environ, PGIBBS_ATTN_F32="valu")
+    p = subprocess.run([sys.executable, "-c", _CHILD % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, env=env,
+                       timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "valu kernels OK" in p.stdout
