@@ -22,7 +22,7 @@ N = 1 result: rank 0 re-runs the whole job on its own GPU after the timed region
 
 Output: ONE JSON line (rank 0) with the driver's contract plus
   roofline     -- the GEMM kernel family (96.5 % of the FLOPs): executed FLOPs / HIP-event time on the engine's stream
-  strict_mode  -- (N = 1) the same workload in the parity mode (PG_PREC_FP32: split-bf16 x3 GEMMs, fp32 attention): its
+  strict_mode  -- (N = 1) the same workload in the parity mode (PG_PREC_FP32: split-bf16 x3 GEMMs and attention): its
                   positions/s and its measured max |logit error| against the fp32 oracle -- the mode north_star's 1e-3
                   tolerance refers to; `bf16_max_abs_logit_err` is the same measurement for the benchmarked mode
   cpu_baseline -- the fp32 CPU oracle (numpy/OpenBLAS port of the same path; the checker, never the product) on a bounded
@@ -309,7 +309,7 @@ def main():
                                   % (B_total, "/".join(str(c) for c in sorted(set(counts))), L, T, P, top_k,
                                      "inf" if burnin == float("inf") else int(burnin),
                                      "bf16 MFMA operands, fp32 accumulate + fp32 residual stream" if args.precision == "bf16"
-                                     else "strict mode: split-bf16 x3 MFMA GEMMs, fp32 attention/softmax/LayerNorm"),
+                                     else "strict mode: split-bf16 x3 MFMA GEMMs and attention products, fp32 softmax/LayerNorm/residual"),
                       "global_batch": B_total, "seq_len": L,
                       "parallelism": "chains sharded %d-way (contiguous blocks), 1 %s all-gather at the end"
                                      % (world, "RCCL" if backend == "nccl" else "gloo"),
@@ -384,7 +384,7 @@ def main():
         torch.cuda.synchronize(dev)
         ts = time.perf_counter() - t0
         out["strict_mode"] = {"value": B_total * P * ks / ts, "unit": "sampled positions/s", "ms_per_step": 1e3 * ts / ks, "steps": ks,
-                              "precision": "PG_PREC_FP32: split-bf16 x3 MFMA GEMMs (hi.hi + hi.lo + lo.hi), fp32 attention",
+                              "precision": "PG_PREC_FP32: split-bf16 x3 MFMA products (lo.hi + hi.lo + hi.hi) in the projections and in attention, fp32 accumulation/softmax/LayerNorm",
                               "max_abs_logit_err": None}
     gpu_cfg1 = None
     if rank == 0 and world == 1 and not dry and not args.no_cpu_baseline:

@@ -74,8 +74,9 @@ typedef struct pg_engine pg_engine;
 #define PG_ARCH_MSA1B 2 /* fair-esm MSATransformer (esm_msa1b_t12_100M_UR50S) */
 
 #define PG_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream (throughput mode) */
-#define PG_PREC_FP32 1 /* strict parity mode: every GEMM as three bf16 MFMA GEMMs on (hi, lo) splits of both operands (hi.hi +
-                          hi.lo + lo.hi, fp32 accumulate), fp32 attention; ~5x slower, logits within 1e-3 of the fp32 oracle */
+#define PG_PREC_FP32 1 /* strict parity mode: every matrix product (projections, q.k^T, P.v) as three bf16 MFMA products on
+                          (hi, lo) splits of both operands (lo.hi + hi.lo + hi.hi, fp32 accumulate); fp32 softmax, LayerNorm
+                          and residual stream; ~3x slower, logits within 1e-3 of the fp32 oracle */
 
 typedef struct {
   int32_t arch;

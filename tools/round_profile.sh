@@ -15,3 +15,4 @@ cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/esm1b_cfg2_ke
 head -12 $OUT/esm1b_cfg2_kernel_stats.csv | cut -c1-70,150-230
 bash tools/pmc_traffic.sh $TAG > $OUT/pmc_traffic.log 2>&1; cp gpurun_out/traffic_$TAG.json $OUT/hbm_traffic_pmc.json 2>/dev/null; tail -4 $OUT/pmc_traffic.log
 python bench_msa.py > $OUT/msa_bench.jsonl 2> $OUT/msa_bench.err; cut -c1-400 $OUT/msa_bench.jsonl
+python bench_msa.py --precision fp32 --steps 2 > $OUT/msa_bench_strict.jsonl 2>> $OUT/msa_bench.err; cut -c1-400 $OUT/msa_bench_strict.jsonl
