@@ -22,10 +22,24 @@ namespace pg {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // MAXKB = number of 16-key blocks computed (T <= 16*MAXKB), even.  The dispatch ladder guarantees
 // T > 16*(MAXKB-6), so only the last 6 blocks can hold masked (>= T) keys.
 typedef short v4s __attribute__((ext_vector_type(4)));
+
+// Phase timestamps for tools/probes/attention_phases.hip (compiled out of the library): lane 0 of every wave records the
+// shader clock at the phase boundaries of its first query blocks.
+#ifdef PG_ATT_PROF
+__device__ unsigned long long* pg_att_prof;      // [workgroup][wave][8 slots][8 stamps]
+#define PG_T(slot, i)                                                                                              \
+  do {                                                                                                             \
+    if ((slot) < 8 && (threadIdx.x & 63) == 0)                                                                     \
+      pg_att_prof[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)) * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define PG_T(slot, i)
+#endif
 
 template <int MAXKB, bool PADMASK>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
@@ -36,6 +50,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   char* Vs = smem + MAXKB * 16 * 128;          // V rows, same layout as K: row*128 + ((chunk ^ (row & 7)) << 4)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  PG_T(7, 0);
   // sequence `seq` = token rows row0 + t*row_step (ESM: contiguous rows of chain b; MSA column attention: the R rows
   // of one column, C token-rows apart)
   const int seq = blockIdx.x / H, h = blockIdx.x % H;
@@ -73,7 +88,9 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       }
     }
   }
+  PG_T(7, 1);
   __syncthreads();
+  PG_T(7, 2);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nqb = (T + 15) >> 4;  // query blocks of 16
@@ -89,6 +106,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   if (wave < nqb) load_q(wave, qf);
   for (int qb = wave; qb < nqb; qb += 4) {
     if (qb + 4 < nqb) load_q(qb + 4, qn);
+    PG_T(qb >> 2, 0);
 
     // S^T blocks: st[kb][r] = S[query fr][key kb*16 + fq*4 + r]
     f32x4 st[MAXKB];
@@ -100,7 +118,12 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       auto load_chunk = [&](int ch, bf16x8 (&dst)[CH][2]) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
+#if defined(PG_ATT_PROF) && PG_ATT_ABL == 1      /* ablation: one K fragment read per chunk instead of CH */
+          const int krow = (ch * CH + (u > 0 ? 0 : u)) * 16 + fr;
+          if (u > 0) { dst[u][0] = dst[0][0]; dst[u][1] = dst[0][1]; continue; }
+#else
           const int krow = (ch * CH + u) * 16 + fr;
+#endif
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) dst[u][kk] = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
         }
@@ -110,27 +133,33 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       for (int ch = 0; ch < MAXKB / CH; ++ch) {
         if (ch + 1 < MAXKB / CH) load_chunk(ch + 1, kbuf[(ch + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
+        // the two d-halves of a key block as two sweeps over the chunk, so that no MFMA is issued right behind the one
+        // producing its accumulator input (hipcc otherwise pairs them through one temporary register)
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][0], qf[0], a, 0, 0, 0);
-          st[ch * CH + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][1], qf[1], a, 0, 0, 0);
-        }
+        for (int u = 0; u < CH; ++u)
+          st[ch * CH + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          st[ch * CH + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][1], qf[1], st[ch * CH + u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    PG_T(qb >> 2, 1);
     // exact softmax over keys (lane-local + 4-lane reduction); exp(s - m) = exp2(s*log2e - m*log2e)
     float mx = -3.0e38f;
     int tl = T - fq * 4;                      // key kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
     asm volatile("" : "+v"(tl));              // keep the compares inside the loop (no hoisted lane masks)
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb) {
+    for (int kb = MAXKB > 6 ? MAXKB - 6 : 0; kb < MAXKB; ++kb)
+      if ((kb + 1) * 16 > T) {                // wave-uniform: only key blocks that reach past T are touched
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (kb >= MAXKB - 6 && kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
-        mx = fmaxf(mx, st[kb][r]);
+        for (int r = 0; r < 4; ++r)
+          if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
       }
-    }
+#pragma unroll
+    for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][r]);      // -> v_max3_f32
     if (PADMASK) {
       // ragged batch (only reachable through the forward entry points; the Gibbs path never holds <pad>): keys that are
       // <pad> tokens get -inf like fair-esm's key_padding_mask.  key_tok = the token buffer, sequence `seq` at seq*T.
@@ -146,22 +175,27 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         }
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mneg = -mx * 1.44269504088896341f;
-    float sum = 0.f;
+    mx = rows4_max(mx);
+    // two scores per instruction (v_pk_fma_f32 / v_pk_add_f32): 284 instead of 418 VALU instructions per 16-query block,
+    // 72 of them quarter-rate v_exp_f32
+    const f32x2 l2e = {1.44269504088896341f, 1.44269504088896341f};
+    const float mneg1 = -mx * 1.44269504088896341f;
+    const f32x2 mneg = {mneg1, mneg1};
+    f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < MAXKB; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r], 1.44269504088896341f, mneg));
-        st[kb][r] = e;
-        sum += e;
-      }
+      const f32x2 a = __builtin_elementwise_fma((f32x2){st[kb][0], st[kb][1]}, l2e, mneg);
+      const f32x2 b = __builtin_elementwise_fma((f32x2){st[kb][2], st[kb][3]}, l2e, mneg);
+      const f32x2 ea = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+      const f32x2 eb = {__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
+      st[kb] = (f32x4){ea[0], ea[1], eb[0], eb[1]};
+      sum2 += ea;
+      sum2 += eb;
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    float sum = sum2[0] + sum2[1];
+    sum = rows4_sum(sum);
     const float inv = 1.0f / sum;             // applied to O at the end: the lane's query (fr) is also its O column
+    PG_T(qb >> 2, 2);
 
     // O^T[d][q] = sum_key V^T[d][key] * P^T[key][q]; K-slot (fq*8 + j) of chunk c <-> key (2c + (j>>2))*16 + fq*4 + (j&3)
     f32x4 o[4];
@@ -174,6 +208,9 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       auto load_v = [&](int c, VF (&dst)[4]) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
+#if defined(PG_ATT_PROF) && PG_ATT_ABL == 2      /* ablation: one V^T fragment read per chunk instead of 4 */
+          if (db > 0) { dst[db] = dst[0]; continue; }
+#endif
           // transposed LDS read (semantics probed on the device): the 16 lanes of a group point at 4 key rows x four 8-byte
           // pieces of 16 d (lane s -> row s>>2, piece s&3) and lane fr receives V[key0 .. key0+3][d = db*16 + fr]
 #pragma unroll
@@ -204,6 +241,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    PG_T(qb >> 2, 3);
     // store: lane holds O[q = qb*16 + fr][d = db*16 + fq*4 + r]
     const int q = qb * 16 + fr;
     if (q < T) {
@@ -218,7 +256,9 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
     }
     qf[0] = qn[0];
     qf[1] = qn[1];
+    PG_T(qb >> 2, 4);
   }
+  PG_T(7, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,8 +355,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
           tmax = fmaxf(tmax, st[kb][r]);
         }
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    tmax = rows4_max(tmax);
     const float mn = fmaxf(m, tmax);
     const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
     const float mneg = -mn * LOG2E;
@@ -329,8 +368,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
         st[kb][r] = e;
         psum += e;
       }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
+    psum = rows4_sum(psum);
     l = l * alpha + psum;
     m = mn;
 #pragma unroll

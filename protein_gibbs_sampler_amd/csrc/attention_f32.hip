@@ -131,8 +131,7 @@ struct SplitAttn {
     for (int kb = 0; kb < MAXKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[kb][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    tmax = rows4_max(tmax);
     const float mn = fmaxf(m, tmax);
     const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
     const float mneg = -mn * LOG2E;
@@ -145,8 +144,7 @@ struct SplitAttn {
         st[kb][r] = e;
         psum += e;
       }
-    psum += __shfl_xor(psum, 16);
-    psum += __shfl_xor(psum, 32);
+    psum = rows4_sum(psum);
     l = l * alpha + psum;
     m = mn;
 #pragma unroll

@@ -165,8 +165,7 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
         mx = fmaxf(mx, st[kb][r4]);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = rows4_max(mx);
     const float mneg = -mx * LOG2E;
     float sum = 0.f;
   #pragma unroll
@@ -178,8 +177,7 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
         sum += e;
       }
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = rows4_sum(sum);
     const float inv = 1.0f / sum;
   #pragma unroll
     for (int c = 0; c < MAXKB / 2; ++c) {

@@ -42,6 +42,36 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ bf16_t f32_to_bf16_dev(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+
+// Reductions over the four lanes {l, l^16, l^32, l^48} (the four 16-lane rows of a wave = the fq groups of an MFMA
+// fragment) with gfx950's row-swap VALU instructions instead of two ds_bpermute round trips through the LDS pipe:
+// v_permlane16_swap(a, b) swaps the odd rows of a with the even rows of b, v_permlane32_swap the upper half of a with the
+// lower half of b; with a = b = x the two results hold (x[l], x[l ^ 16 / 32]) in every lane, in either order.
+// Inline asm, not __builtin_amdgcn_permlane16/32_swap: hipcc 7.2 folds op(r[0], r[1]) of the builtin's two results to
+// op(r[0], r[0]) (seen in the ISA; results off by the missing term).  The s_nop covers the "VALU write -> permlane read"
+// hazard (2 wait states), which the compiler does not track through an asm statement.
+__device__ __forceinline__ void rows_swap16(float x, float& a, float& b) {
+  a = x;
+  b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void rows_swap32(float x, float& a, float& b) {
+  a = x;
+  b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rows4_max(float x) {
+  float a, b;
+  rows_swap16(x, a, b);
+  rows_swap32(fmaxf(a, b), a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+  float a, b;
+  rows_swap16(x, a, b);
+  rows_swap32(a + b, a, b);
+  return a + b;
+}
 #endif
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
