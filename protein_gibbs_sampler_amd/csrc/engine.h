@@ -66,7 +66,7 @@ struct Engine {
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask
-  float* splitk_ws(int rows, int n);
+  float* splitk_ws(int rows, int n, int64_t batch_rows);
   // launch-bound (small) Gibbs loops: one iteration captured as a hipGraph and replayed; the iteration number lives in
   // d_iter on the device, so the same graph serves every iteration
   DevBuf d_iter;

@@ -236,8 +236,12 @@ int Engine::dense3(const bf16_t* x3, const DenseW& W, float* out, int Mp, bool a
 // ESM-1b forward: tokens[B][T] -> x[B*T][d] (residual stream before emb_layer_norm_after)
 // ------------------------------------------------------------------------------------------------
 // Scratch for the split-K form of a small fc2 GEMM (launch_gemm_bf16 decides whether to use it); nullptr for large M.
-float* Engine::splitk_ws(int rows, int n) {
-  if (rows > 2048) return nullptr;
+// A K-split sums in a different order than the one-pass kernels, so the decision must not depend on how a batch is sharded:
+// it is taken on the forward's token rows M (`batch_rows`), also for the pruned last layer whose GEMMs see only the B*P selected
+// rows -- a 32-chain shard of config 3 (8256 token rows, 800 selected) must give the same logits bit for bit as the whole
+// 256-chain batch (6400 selected), and did not while this looked at the selected rows.
+float* Engine::splitk_ws(int rows, int n, int64_t batch_rows) {
+  if (rows > 2048 || batch_rows > 2048) return nullptr;
   const size_t need = (size_t)5 * round_up(rows, kRowPad) * n * 4;
   if (splitk.bytes < need && splitk.ensure(need, stream)) return nullptr;
   return splitk.as<float>();
@@ -318,13 +322,13 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.out.w, L.out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
       if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln2.g, L.ln2.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, M), splitk.bytes); }))) return rc;
       break;
     }
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d), splitk.bytes); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, M), splitk.bytes); }))) return rc;
   }
   return PG_OK;
 }
@@ -535,14 +539,14 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.col_out.w, L.col_out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
       if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln_ffn.g, L.ln_ffn.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, M), splitk.bytes); }))) return rc;
       break;
     }
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.col_out.w, L.col_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
     // feed forward
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_ffn.g, L.ln_ffn.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d), splitk.bytes); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, M), splitk.bytes); }))) return rc;
   }
   return PG_OK;
 }

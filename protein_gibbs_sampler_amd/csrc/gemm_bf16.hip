@@ -65,6 +65,26 @@ __device__ __forceinline__ float gelu_bf16out(float x) {
   return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
 }
 
+// The same function on two values at once: the polynomial and the final multiply-add as v_pk_fma_f32 (two fp32 per
+// instruction).  Per element 1 (abs) + 2.5 + 4 (quarter-rate v_exp_f32) + 0.5 + 1 (max) = 9 issue slots instead of 12; the
+// arithmetic per element is identical (same fma chain), so results do not change.  Packs the pair to bf16.
+typedef __attribute__((ext_vector_type(2))) float pg_f32x2;
+__device__ __forceinline__ uint32_t gelu_bf16out_pack2(float x0, float x1) {
+  const pg_f32x2 x = {x0, x1};
+  const pg_f32x2 t = {fabsf(x0), fabsf(x1)};
+  pg_f32x2 p = {-4.074793151e-04f, -4.074793151e-04f};
+  p = __builtin_elementwise_fma(p, t, (pg_f32x2){6.563348950e-03f, 6.563348950e-03f});
+  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-5.032995553e-02f, -5.032995553e-02f});
+  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-4.618885100e-01f, -4.618885100e-01f});
+  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-1.149779793e+00f, -1.149779793e+00f});
+  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-1.000206717e+00f, -1.000206717e+00f});
+  const pg_f32x2 e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+  const pg_f32x2 r = {fmaxf(x0, 0.f), fmaxf(x1, 0.f)};
+  const pg_f32x2 g = __builtin_elementwise_fma(-t, e, r);
+  (void)x;
+  return pack_bf16x2(g[0], g[1]);
+}
+
 // Stage ROWS x 64 bf16 (128 B per row) into LDS.  One wave-instruction = 8 rows = 1 KiB, written
 // lane-linearly; lane l covers row (l>>3), LDS chunk (l&7), which receives global chunk (l&7)^(row&7).
 template <int ROWS, int NW>
@@ -160,11 +180,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
       const int m = m0 + wm * WM + j * 16 + fr;
       float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
       if (EPI == EPI_F32_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-      if (EPI == EPI_BF16_GELU) { v0 = gelu_bf16out(v0); v1 = gelu_bf16out(v1); v2 = gelu_bf16out(v2); v3 = gelu_bf16out(v3); }
       if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
         uint2 p;
-        p.x = pack_bf16x2(v0, v1);
-        p.y = pack_bf16x2(v2, v3);
+        // every tile kernel sends the fc1 GELU through the same packed routine: rows stay bit-identical for any batch split
+        p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
+        p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
         *(uint2*)((bf16_t*)out + (size_t)m * ldo + n) = p;
       } else if (EPI == EPI_F32_RESID) {
         float4* o = (float4*)((float*)out + (size_t)m * ldo + n);
@@ -252,10 +272,10 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
           const float4 a = *(const float4*)(smem + sr * 1024 + (((2 * c8) ^ (sr & 63)) << 4));
           const float4 b = *(const float4*)(smem + sr * 1024 + (((2 * c8 + 1) ^ (sr & 63)) << 4));
           uint4 v;
-          v.x = pack_bf16x2(gelu_bf16out(a.x), gelu_bf16out(a.y));
-          v.y = pack_bf16x2(gelu_bf16out(a.z), gelu_bf16out(a.w));
-          v.z = pack_bf16x2(gelu_bf16out(b.x), gelu_bf16out(b.y));
-          v.w = pack_bf16x2(gelu_bf16out(b.z), gelu_bf16out(b.w));
+          v.x = gelu_bf16out_pack2(a.x, a.y);
+          v.y = gelu_bf16out_pack2(a.z, a.w);
+          v.z = gelu_bf16out_pack2(b.x, b.y);
+          v.w = gelu_bf16out_pack2(b.z, b.w);
           PG_EPI_STORE((uint4*)(ob + (size_t)r2 * ldo + c8 * 8), v);
         }
       }
@@ -517,11 +537,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, int abl = 0) {
   // the big-tile kernel of the default dispatch: PGIBBS_GEMM_BIG=w4 / w16: the 4-wave / 16-wave kernel of gemm_w4.hip / gemm_w16.hip, default (pp) this one
-  // -1 (default): per shape -- the 16-wave kernel for the plain bf16 epilogue (QKV projections: 3.5-4 % faster there), this one
-  // for the rest (the 16-wave kernel loses 3-4 % on the N = d residual GEMMs); 0 = always this one, 4 / 16 = always that kernel
+  // -1 (default): per epilogue -- the 16-wave kernel for the bf16 outputs (QKV projections: 3.5-4 % faster there; fc1: its
+  // one-pass GELU epilogue is 0.03 ms shorter per launch), this one for the fp32 residual GEMMs (the 16-wave kernel loses
+  // 3-4 % on those); 0 = always this one, 4 / 16 = always that kernel
   static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? (e[1] == '1' ? 16 : 4) : 0); }();
   if (!abl && big == 4 && K >= 128) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
-  if (!abl && (big == 16 || (big == -1 && epi == EPI_BF16))) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
+  if (!abl && (big == 16 || (big == -1 && (epi == EPI_BF16 || epi == EPI_BF16_GELU)))) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles), block(512);
   if (abl) {   // ablations: EPI_BF16 only
@@ -651,12 +672,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
     }
     float v0 = v[0] + b4.x, v1 = v[1] + b4.y, v2 = v[2] + b4.z, v3 = v[3] + b4.w;
     if (EPI == EPI_F32_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-    if (EPI == EPI_BF16_GELU) { v0 = gelu_bf16out(v0); v1 = gelu_bf16out(v1); v2 = gelu_bf16out(v2); v3 = gelu_bf16out(v3); }
     const size_t o = (size_t)(t * 16 + fr) * ldo + n0 + fq * 4;
     if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
       uint2 p;
-      p.x = pack_bf16x2(v0, v1);
-      p.y = pack_bf16x2(v2, v3);
+      p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
+      p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
       *(uint2*)((bf16_t*)out + o) = p;
     } else if (EPI == EPI_F32_RESID) {
       float4* dst = (float4*)((float*)out + o);

@@ -60,6 +60,10 @@ __device__ __forceinline__ void rows_swap32(float x, float& a, float& b) {
   b = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+#ifdef PG_ROWS4_SHFL   /* bisecting aid: the ds_bpermute form */
+__device__ __forceinline__ float rows4_max(float x) { x = fmaxf(x, __shfl_xor(x, 16)); return fmaxf(x, __shfl_xor(x, 32)); }
+__device__ __forceinline__ float rows4_sum(float x) { x += __shfl_xor(x, 16); return x + __shfl_xor(x, 32); }
+#else
 __device__ __forceinline__ float rows4_max(float x) {
   float a, b;
   rows_swap16(x, a, b);
@@ -72,6 +76,7 @@ __device__ __forceinline__ float rows4_sum(float x) {
   rows_swap32(a + b, a, b);
   return a + b;
 }
+#endif
 #endif
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }

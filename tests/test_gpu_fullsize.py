@@ -119,16 +119,21 @@ def test_config3_shards_reproduce_the_single_gpu_gibbs_run(sampler):
         params = _lib.make_sample_params(True, 32, 0, float("inf"), 1.0, sampler.valid_aa_idx, rng_seed=0, row_id_base=lo)
         d_tok = torch.from_numpy(tok_all[lo:hi].copy()).cuda()
         d_idx = torch.from_numpy(table).cuda()
+        d_lg = torch.empty((iters, hi - lo, P, 33), dtype=torch.float32, device="cuda")
         _lib.check(L_.pg_esm_gibbs_run_device(lm.handle, ctypes.c_void_p(d_tok.data_ptr()), hi - lo, T,
-                                              ctypes.c_void_p(d_idx.data_ptr()), iters, P, ctypes.byref(params), None, None))
+                                              ctypes.c_void_p(d_idx.data_ptr()), iters, P, ctypes.byref(params),
+                                              ctypes.c_void_p(d_lg.data_ptr()), None))
         lm.synchronize()
-        return d_tok.cpu().numpy()
+        return d_tok.cpu().numpy(), d_lg.cpu().numpy()
 
-    whole = run(0, B)
+    whole, whole_lg = run(0, B)
     assert (whole != tok_all).any()
-    for world in (8, 2):
+    for world in (8, 4, 2):
         parts = [run(*sharding.shard_range(B, world, g)) for g in range(world)]
-        assert (np.concatenate(parts) == whole).all(), "world=%d" % world
+        # the logits every draw was made from, bit for bit (equal tokens alone could be luck: a 1e-3 logit difference -- a K-split
+        # fc2 on a shard's 800 selected rows did that until round 2 -- flips only one draw in a few thousand)
+        assert (np.concatenate([p[1] for p in parts], axis=1) == whole_lg).all(), "world=%d: sampled-position logits differ" % world
+        assert (np.concatenate([p[0] for p in parts]) == whole).all(), "world=%d" % world
 
 
 def test_config4_full_size_msa_gibbs_properties():
