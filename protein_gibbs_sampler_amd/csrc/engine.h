@@ -67,6 +67,8 @@ struct Engine {
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask
   float* splitk_ws(int rows, int n, int64_t batch_rows);
+  int64_t batch_rows = 0;                  // token rows of the forward in flight (set by the trunks)
+  int sel_gemm_rows(int64_t n_sel, int64_t Np) const;
   // launch-bound (small) Gibbs loops: one iteration captured as a hipGraph and replayed; the iteration number lives in
   // d_iter on the device, so the same graph serves every iteration
   DevBuf d_iter;

@@ -236,6 +236,15 @@ int Engine::dense3(const bf16_t* x3, const DenseW& W, float* out, int Mp, bool a
 // ESM-1b forward: tokens[B][T] -> x[B*T][d] (residual stream before emb_layer_norm_after)
 // ------------------------------------------------------------------------------------------------
 // Scratch for the split-K form of a small fc2 GEMM (launch_gemm_bf16 decides whether to use it); nullptr for large M.
+// GEMM height for the B*P selected rows (pruned last layer, LM head).  Up to 48 rows would take the weight-streaming kernel,
+// whose k order differs from the tile kernels': fine for a few chains (its regime), but in a big batch the height is raised
+// to one 64-row tile so that the selected rows of a shard and of the whole batch see the same arithmetic.
+int Engine::sel_gemm_rows(int64_t n_sel, int64_t Np) const {
+  if (n_sel > 256) return (int)Np;
+  const int r = round_up((int)n_sel, 16);
+  return (batch_rows > 2048 && r < 64) ? 64 : r;
+}
+
 // A K-split sums in a different order than the one-pass kernels, so the decision must not depend on how a batch is sharded:
 // it is taken on the forward's token rows M (`batch_rows`), also for the pruned last layer whose GEMMs see only the B*P selected
 // rows -- a 32-chain shard of config 3 (8256 token rows, 800 selected) must give the same logits bit for bit as the whole
@@ -252,6 +261,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   const int64_t M = (int64_t)B * T;
   const int64_t Mp = round_up64(M, kRowPad);
   if (Mp > 0x7fffffff / 4) return fail(PG_ERR_INVALID, "too many tokens in one call");
+  batch_rows = M;
   int rc;
   if (strict()) {
     if ((rc = x.ensure((size_t)Mp * d * 4, stream))) return rc;
@@ -312,7 +322,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       if ((rc = x_sel.ensure((size_t)Np * d * 4, stream)) || (rc = ctx_sel.ensure((size_t)Np * d * 2, stream)) ||
           (rc = h_sel.ensure((size_t)Np * d * 2, stream)) || (rc = ffn_sel.ensure((size_t)Np * f * 2, stream))) return rc;
       float* XS = x_sel.as<float>();
-      const int Ni = n_sel <= 256 ? round_up((int)n_sel, 16) : (int)Np;
+      const int Ni = sel_gemm_rows(n_sel, Np);
       rc = timed(PC_HEAD, [&] {
         int r2 = launch_gather_rows(stream, X, XS, sel_idx, nullptr, P, T, n_sel, d * 4, d_iter_);
         if (r2) return r2;
@@ -357,7 +367,7 @@ int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int wid
                                   sel_h.as<bf16_t>(), n_sel, d, eps);
     if (r) return r;
     r = launch_gemm_bf16(stream, sel_h.as<bf16_t>(), head_dense.w, head_dense.b, sel_g.as<float>(),
-                         n_sel <= 256 ? round_up((int)n_sel, 16) : (int)Np, d, d, d, d, d, EPI_F32_GELU);
+                         sel_gemm_rows(n_sel, Np), d, d, d, d, d, EPI_F32_GELU);
     if (r) return r;
     return launch_lm_tail(stream, sel_g.as<float>(), head_ln.g, head_ln.b, embed, head_bias, d_logits, n_sel, d, V, eps);
   });
@@ -441,6 +451,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   const int64_t M = (int64_t)B * R * C;
   const int64_t Mp = round_up64(M, kRowPad);
   if (Mp > 0x7fffffff / 4) return fail(PG_ERR_INVALID, "too many tokens in one call");
+  batch_rows = M;
   int rc;
   if ((rc = x.ensure((size_t)Mp * d * 4, stream))) return rc;
   if ((rc = h.ensure((size_t)Mp * d * 2, stream))) return rc;

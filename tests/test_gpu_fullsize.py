@@ -99,13 +99,13 @@ def test_config2_full_size_rows_are_independent(sampler):
     assert d < 0.05
 
 
-def test_config3_shards_reproduce_the_single_gpu_gibbs_run(sampler):
-    """The whole Gibbs job of config 2, re-run as the eight 32-chain shards config 3 puts on eight GPUs (here one after the
-    other on one GPU, each with its slice of the one position stream and its global chain ids): final tokens identical."""
+def _sharded_gibbs(sampler, B, P, iters, worlds):
+    """Run the B-chain job whole and as `world` contiguous shards (one after the other on this GPU, each with its slice of the
+    one position stream and its global chain ids); returns nothing, asserts tokens AND the logits of every draw bit for bit."""
     import ctypes
     import torch
     from protein_gibbs_sampler_amd import _lib, pyrandom, sharding
-    B, L, P, iters = 256, 256, 25, 3
+    L = 256
     T = L + 2
     rng = np.random.default_rng(1234)
     tok_all = np.concatenate([np.zeros((B, 1), np.int64), rng.integers(4, 24, (B, L)), np.full((B, 1), 2)], axis=1).astype(np.int32)
@@ -128,12 +128,25 @@ def test_config3_shards_reproduce_the_single_gpu_gibbs_run(sampler):
 
     whole, whole_lg = run(0, B)
     assert (whole != tok_all).any()
-    for world in (8, 4, 2):
+    for world in worlds:
         parts = [run(*sharding.shard_range(B, world, g)) for g in range(world)]
         # the logits every draw was made from, bit for bit (equal tokens alone could be luck: a 1e-3 logit difference -- a K-split
         # fc2 on a shard's 800 selected rows did that until round 2 -- flips only one draw in a few thousand)
-        assert (np.concatenate([p[1] for p in parts], axis=1) == whole_lg).all(), "world=%d: sampled-position logits differ" % world
-        assert (np.concatenate([p[0] for p in parts]) == whole).all(), "world=%d" % world
+        assert (np.concatenate([p[1] for p in parts], axis=1) == whole_lg).all(), "B=%d P=%d world=%d: sampled-position logits differ" % (B, P, world)
+        assert (np.concatenate([p[0] for p in parts]) == whole).all(), "B=%d P=%d world=%d" % (B, P, world)
+
+
+def test_config3_shards_reproduce_the_single_gpu_gibbs_run(sampler):
+    """The whole Gibbs job of config 2, re-run as the 32- / 64- / 128-chain shards config 3 puts on 8 / 4 / 2 GPUs."""
+    _sharded_gibbs(sampler, 256, 25, 3, (8, 4, 2))
+
+
+@pytest.mark.parametrize("B,P", [(64, 1), (64, 5), (128, 3)])
+def test_shards_with_few_selected_rows(sampler, B, P):
+    """Shards whose B*P selected rows are few (8 to 48: the shapes that would pick the weight-streaming GEMM or a K-split for the
+    pruned last layer and the LM head) against the whole batch (64 to 384 selected rows: tile kernels).  The contract
+    (DESIGN.md section 7): bit-identical for any contiguous split whose shards each hold more than 2048 token rows."""
+    _sharded_gibbs(sampler, B, P, 2, (8,))
 
 
 def test_config4_full_size_msa_gibbs_properties():

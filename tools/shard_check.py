@@ -12,13 +12,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from protein_gibbs_sampler_amd import _lib, models, pyrandom, sharding, weights  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+B_ARG = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+P_ARG = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 cfg = dict(weights.ESM1B_CONFIG)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     wrapper = models.ESM1b(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg)
 lm = wrapper.model.to("cuda:0")
 valid = sorted(wrapper.alphabet.get_idx(t) for t in "ACDEFGHIKLMNPQRSTVWY")
-B, L, P = 256, 256, 25
+B, L, P = B_ARG, 256, P_ARG
 T = L + 2
 rng = np.random.default_rng(1234)
 tok_all = np.concatenate([np.zeros((B, 1), np.int64), rng.integers(4, 24, (B, L)), np.full((B, 1), 2)], axis=1).astype(np.int32)
