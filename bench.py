@@ -275,6 +275,8 @@ def main():
         if not dry:
             torch.cuda.synchronize(dev)
 
+    if not dry:
+        lm.set_job_items(B_total)     # rank's chains are a shard of the B_total-chain job: same kernel choices as the single-GPU run
     job = Job(lm, lo, hi)
     if W > 0:
         keep = job.run(W)

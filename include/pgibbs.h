@@ -106,6 +106,13 @@ void pg_engine_destroy(pg_engine*);
 int pg_engine_set_stream(pg_engine*, void* hip_stream);
 int pg_engine_synchronize(pg_engine*);
 int pg_engine_device(const pg_engine*);
+/* Multi-GPU jobs (contiguous blocks of chains / MSAs per GPU): the number of batch items (chains, MSAs) of the
+ * WHOLE job this engine's calls are a shard of; 0 (default) = every call is a whole job.  Kernel choices that change the
+ * order of a floating-point sum (K-split GEMMs and the weight-streaming GEMM of the few-chain regime, the row-split form of
+ * the tied row attention) are then taken on the job's size instead of the shard's, so that every shard computes bit for bit
+ * what a single engine computes on the whole batch (jobs with more than 2048 token rows; smaller jobs run in the few-chain
+ * regime whose kernels are picked by the local shape).  No effect on results of a call that is a whole job. */
+int pg_engine_set_job_items(pg_engine*, int64_t job_items);
 
 /* Sampling parameters == the kwargs of generate() that reach generate_step
  * (src/pgen/esm_sampler.py:8-45, 227-232). */

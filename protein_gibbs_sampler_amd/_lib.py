@@ -71,6 +71,7 @@ SIGNATURES = [
     ("pg_engine_set_stream", c_int, [c_void_p, c_void_p]),
     ("pg_engine_synchronize", c_int, [c_void_p]),
     ("pg_engine_device", c_int, [c_void_p]),
+    ("pg_engine_set_job_items", c_int, [c_void_p, c_int64]),
     ("pg_esm_forward_logits", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     ("pg_esm_gibbs_run", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(SampleParams), c_void_p,
                                  c_void_p]),

@@ -91,6 +91,12 @@ int pg_engine_synchronize(pg_engine* h) {
   return PG_OK;
 }
 int pg_engine_device(const pg_engine* h) { return h ? h->e.device : -1; }
+int pg_engine_set_job_items(pg_engine* h, int64_t job_items) {
+  if (!h) return fail(PG_ERR_INVALID, "null engine");
+  if (job_items < 0) return fail(PG_ERR_INVALID, "pg_engine_set_job_items: negative count");
+  h->e.job_items = job_items;
+  return PG_OK;
+}
 
 // ---- ESM-1b ---------------------------------------------------------------------------------
 int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, float* logits_out) {

@@ -67,7 +67,9 @@ struct Engine {
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask
   float* splitk_ws(int rows, int n, int64_t batch_rows);
-  int64_t batch_rows = 0;                  // token rows of the forward in flight (set by the trunks)
+  int64_t job_items = 0;                   // pg_engine_set_job_items: batch items of the whole (multi-GPU) job, 0 = this call
+  int64_t job_batch(int64_t B) const { return job_items > B ? job_items : B; }
+  int64_t batch_rows = 0;                  // token rows of the JOB's forward (job_batch(B) x rows per item; set by the trunks)
   int sel_gemm_rows(int64_t n_sel, int64_t Np) const;
   // launch-bound (small) Gibbs loops: one iteration captured as a hipGraph and replayed; the iteration number lives in
   // d_iter on the device, so the same graph serves every iteration

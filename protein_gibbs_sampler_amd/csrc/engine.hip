@@ -261,7 +261,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   const int64_t M = (int64_t)B * T;
   const int64_t Mp = round_up64(M, kRowPad);
   if (Mp > 0x7fffffff / 4) return fail(PG_ERR_INVALID, "too many tokens in one call");
-  batch_rows = M;
+  batch_rows = job_batch(B) * T;
   int rc;
   if (strict()) {
     if ((rc = x.ensure((size_t)Mp * d * 4, stream))) return rc;
@@ -304,7 +304,9 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   bf16_t* CTX = ctx.as<bf16_t>();
   bf16_t* FFN = ffn.as<bf16_t>();
   const float eps = cfg.layer_norm_eps;
-  const int Mi = M <= 256 ? round_up((int)M, 16) : (int)Mp;  // <= 256 rows: weight-streaming skinny GEMM (buffers stay 256-padded)
+  // <= 256 rows: 64-row tiles, <= 48 rows the weight-streaming GEMM (buffers stay 256-padded) -- the latter not for a tiny shard
+  // of a big job (sel_gemm_rows)
+  const int Mi = sel_gemm_rows(M, Mp);
 
   rc = timed(PC_EMBED, [&] {
     return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
@@ -332,13 +334,13 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.out.w, L.out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
       if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln2.g, L.ln2.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, M), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
     }
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, M), splitk.bytes); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
   }
   return PG_OK;
 }
@@ -451,7 +453,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   const int64_t M = (int64_t)B * R * C;
   const int64_t Mp = round_up64(M, kRowPad);
   if (Mp > 0x7fffffff / 4) return fail(PG_ERR_INVALID, "too many tokens in one call");
-  batch_rows = M;
+  batch_rows = job_batch(B) * R * C;
   int rc;
   if ((rc = x.ensure((size_t)Mp * d * 4, stream))) return rc;
   if ((rc = h.ensure((size_t)Mp * d * 2, stream))) return rc;
@@ -513,7 +515,9 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if (C <= 576) {
       float* part = nullptr;
-      if (B * H * ((C + 63) / 64) < 384 && R >= 8) {      // few workgroups: give the kernel scratch for its split-R mode
+      // few workgroups: give the kernel scratch for its split-R mode (decided on the job's batch: the split changes the
+      // order of the sum over alignment rows, and a shard must compute what the whole batch would)
+      if (job_batch(B) * H * ((C + 63) / 64) < 384 && R >= 8) {
         const size_t need = (size_t)B * H * 16 * C * 576 * 4 + (size_t)B * H * (C / 16 + 9) * 18 * 1024;   // partial maps + P fragments
         if (need <= ((size_t)1 << 31) && !(rc = scores.ensure(need, stream))) part = scores.as<float>();
       }
@@ -550,14 +554,14 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.col_out.w, L.col_out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
       if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln_ffn.g, L.ln_ffn.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, M), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
     }
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.col_out.w, L.col_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
     // feed forward
     if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_ffn.g, L.ln_ffn.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, M), splitk.bytes); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
   }
   return PG_OK;
 }

@@ -173,3 +173,8 @@ class NativeMaskedLM:
 
     def synchronize(self):
         _lib.check(_lib.lib().pg_engine_synchronize(self.handle))
+
+    def set_job_items(self, n):
+        """Batch items (chains / MSAs) of the whole multi-GPU job the following calls are shards of; 0 = whole jobs again
+        (pgibbs.h pg_engine_set_job_items: keeps every shard bit-identical with the single-GPU run)."""
+        _lib.check(_lib.lib().pg_engine_set_job_items(self.handle, int(n)))

@@ -155,7 +155,11 @@ class ESM_MSA_sampler():
             if native and ctx is not None:
                 def run_block(ltok, ltable, base):
                     params.row_id_base = base & 0xFFFFFFFF
-                    self.model.model.gibbs_run(ltok, ltable, params)
+                    self.model.model.set_job_items(batch.shape[0])      # shard of a batch.shape[0]-item job
+                    try:
+                        self.model.model.gibbs_run(ltok, ltable, params)
+                    finally:
+                        self.model.model.set_job_items(0)
                 tok = sharding.run_sharded(ctx, np.ascontiguousarray(batch.numpy(), dtype=np.int32), table,
                                            generation_round * batch_size * num_sequences, num_sequences, run_block, self.device)
                 batch = torch.from_numpy(tok.astype(np.int64))

@@ -99,7 +99,7 @@ def test_config2_full_size_rows_are_independent(sampler):
     assert d < 0.05
 
 
-def _sharded_gibbs(sampler, B, P, iters, worlds):
+def _sharded_gibbs(sampler, B, P, iters, worlds, job_items=False):
     """Run the B-chain job whole and as `world` contiguous shards (one after the other on this GPU, each with its slice of the
     one position stream and its global chain ids); returns nothing, asserts tokens AND the logits of every draw bit for bit."""
     import ctypes
@@ -120,10 +120,15 @@ def _sharded_gibbs(sampler, B, P, iters, worlds):
         d_tok = torch.from_numpy(tok_all[lo:hi].copy()).cuda()
         d_idx = torch.from_numpy(table).cuda()
         d_lg = torch.empty((iters, hi - lo, P, 33), dtype=torch.float32, device="cuda")
-        _lib.check(L_.pg_esm_gibbs_run_device(lm.handle, ctypes.c_void_p(d_tok.data_ptr()), hi - lo, T,
-                                              ctypes.c_void_p(d_idx.data_ptr()), iters, P, ctypes.byref(params),
-                                              ctypes.c_void_p(d_lg.data_ptr()), None))
-        lm.synchronize()
+        if job_items:
+            lm.set_job_items(B)              # as the samplers and bench.py do on every rank (pgibbs.h pg_engine_set_job_items)
+        try:
+            _lib.check(L_.pg_esm_gibbs_run_device(lm.handle, ctypes.c_void_p(d_tok.data_ptr()), hi - lo, T,
+                                                  ctypes.c_void_p(d_idx.data_ptr()), iters, P, ctypes.byref(params),
+                                                  ctypes.c_void_p(d_lg.data_ptr()), None))
+            lm.synchronize()
+        finally:
+            lm.set_job_items(0)
         return d_tok.cpu().numpy(), d_lg.cpu().numpy()
 
     whole, whole_lg = run(0, B)
@@ -145,8 +150,17 @@ def test_config3_shards_reproduce_the_single_gpu_gibbs_run(sampler):
 def test_shards_with_few_selected_rows(sampler, B, P):
     """Shards whose B*P selected rows are few (8 to 48: the shapes that would pick the weight-streaming GEMM or a K-split for the
     pruned last layer and the LM head) against the whole batch (64 to 384 selected rows: tile kernels).  The contract
-    (DESIGN.md section 7): bit-identical for any contiguous split whose shards each hold more than 2048 token rows."""
+    (DESIGN.md section 7): without being told the job's size, bit-identical for any contiguous split whose shards each hold
+    more than 2048 token rows."""
     _sharded_gibbs(sampler, B, P, 2, (8,))
+
+
+@pytest.mark.parametrize("B,P,world", [(24, 2, 8), (16, 25, 16), (256, 25, 8)])
+def test_shards_that_know_the_job_size(sampler, B, P, world):
+    """With pg_engine_set_job_items (what ESM_sampler.generate and bench.py do on every rank) every contiguous split of a job
+    with more than 2048 token rows is bit-identical with the single-engine run -- also three chains or one chain per shard,
+    where a shard on its own would pick the few-chain kernels (weight streaming, K-splits) and land 1e-2 away."""
+    _sharded_gibbs(sampler, B, P, 2, (world,), job_items=True)
 
 
 def test_config4_full_size_msa_gibbs_properties():
@@ -189,3 +203,49 @@ def test_config4_full_size_msa_gibbs_properties():
     lm = m.model
     full = lm.forward_logits(start[:16])
     assert (lm.forward_logits(start[:8]) == full[:8]).all() and (lm.forward_logits(start[8:16]) == full[8:16]).all()
+
+
+@pytest.mark.parametrize("B,R,L,P,worlds", [(8, 8, 100, 3, (8, 2)), (4, 16, 256, 5, (4,)), (16, 32, 256, 25, (16,))])
+def test_msa_shards_reproduce_the_single_gpu_gibbs_run(B, R, L, P, worlds):
+    """ESM-MSA-1b at full size: B MSAs whole vs contiguous shards that know the job's size -- tokens and the logits of every draw
+    bit for bit.  One or two MSAs per shard on their own would take the row-split form of the tied row attention (sum over
+    alignment rows in chunks) where the whole batch does not; the decision is taken on the job's batch."""
+    import ctypes
+    import torch
+    from protein_gibbs_sampler_amd import _lib, pyrandom, sharding
+    cfg = dict(weights.MSA1B_CONFIG)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wrapper = models.ESM_MSA1(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg)
+    lm = wrapper.model.to("cuda:0")
+    valid = sorted(wrapper.alphabet.get_idx(t) for t in "-ACDEFGHIKLMNPQRSTVWY")
+    rng = np.random.default_rng(1234)
+    C, iters = L + 1, 2
+    aa = np.asarray(valid[:20])[rng.integers(0, 20, (B, R, L))]
+    tok_all = np.concatenate([np.zeros((B, R, 1), np.int64), aa], axis=2).astype(np.int32)
+    L_ = _lib.lib()
+
+    def run(lo, hi):
+        r = pyrandom.NativePyRandom()
+        r.seed(0)
+        table = r.sample_table(list(range(1, L + 1)), P, iters * B * R).reshape(iters, B, R, P)[:, lo:hi].copy()
+        params = _lib.make_sample_params(True, cfg["mask_idx"], 0, float("inf"), 1.0, valid, rng_seed=0, row_id_base=lo * R)
+        d_tok = torch.from_numpy(tok_all[lo:hi].copy()).cuda()
+        d_idx = torch.from_numpy(table).cuda()
+        d_lg = torch.empty((iters, hi - lo, R, P, 33), dtype=torch.float32, device="cuda")
+        lm.set_job_items(B)
+        try:
+            _lib.check(L_.pg_msa_gibbs_run_device(lm.handle, ctypes.c_void_p(d_tok.data_ptr()), hi - lo, R, C,
+                                                  ctypes.c_void_p(d_idx.data_ptr()), iters, P, ctypes.byref(params),
+                                                  ctypes.c_void_p(d_lg.data_ptr()), None))
+            lm.synchronize()
+        finally:
+            lm.set_job_items(0)
+        return d_tok.cpu().numpy(), d_lg.cpu().numpy()
+
+    whole, whole_lg = run(0, B)
+    assert (whole != tok_all).any()
+    for world in worlds:
+        parts = [run(*sharding.shard_range(B, world, g)) for g in range(world)]
+        assert (np.concatenate([p[1] for p in parts], axis=1) == whole_lg).all(), "world=%d: sampled-position logits differ" % world
+        assert (np.concatenate([p[0] for p in parts]) == whole).all(), "world=%d" % world

@@ -30,6 +30,7 @@ L_ = _lib.lib()
 def run(lo, hi, n=iters, want_logits=False):
     r = pyrandom.NativePyRandom()
     r.seed(0)
+    lm.set_job_items(B)                      # this call is a shard of the B-item job (pgibbs.h pg_engine_set_job_items)
     table = sharding.local_slice(sharding.global_position_table(r, list(range(1, L + 1)), P, n, B), lo, hi)
     params = _lib.make_sample_params(True, 32, 0, float("inf"), 1.0, valid, rng_seed=0, row_id_base=lo)
     d_tok = torch.from_numpy(tok_all[lo:hi].copy()).cuda()
@@ -38,6 +39,7 @@ def run(lo, hi, n=iters, want_logits=False):
     _lib.check(L_.pg_esm_gibbs_run_device(lm.handle, ctypes.c_void_p(d_tok.data_ptr()), hi - lo, T, ctypes.c_void_p(d_idx.data_ptr()), n, P,
                                           ctypes.byref(params), ctypes.c_void_p(lg.data_ptr()) if want_logits else None, None))
     lm.synchronize()
+    lm.set_job_items(0)
     return d_tok.cpu().numpy(), (lg.cpu().numpy() if want_logits else None)
 
 
