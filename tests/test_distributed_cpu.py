@@ -95,6 +95,10 @@ def _fake_engine_model(msa):
     class FakeLM(NativeMaskedLM):
         def __init__(self):
             self.calls = []
+            self.job_items = []
+
+        def set_job_items(self, n):          # the samplers announce the whole batch around every shard call and reset it
+            self.job_items.append(int(n))
 
         def eval(self):
             return self
@@ -135,7 +139,7 @@ def _generate_both(seed):
     m = esm_msa_sampler.ESM_MSA_sampler(_fake_engine_model(True), device="gpu")
     m.draw_seed = 12
     b = m.generate(11, ["MEPAATGQ", "MEP-ATGQ"], batch_size=3, num_iters=2, num_positions=3, show_progress_bar=False)
-    return a, b, random.getrandbits(32), s.model.model.calls, m.model.model.calls
+    return a, b, random.getrandbits(32), s.model.model.calls, m.model.model.calls, s.model.model.job_items, m.model.model.job_items
 
 
 def _gen_worker(rank, world, port, q):
@@ -148,8 +152,9 @@ def _gen_worker(rank, world, port, q):
 
 
 def test_generate_shards_batches_over_two_ranks():
-    want_a, want_b, want_state, calls_a, calls_b = _generate_both(seed=1)
+    want_a, want_b, want_state, calls_a, calls_b, ja, jb = _generate_both(seed=1)
     assert calls_a == [(5, 24)] * 2 and calls_b == [(3, 2, 9)] * 2
+    assert ja == [] and jb == []                              # one process: every call is a whole job
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -161,7 +166,9 @@ def test_generate_shards_batches_over_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank in (0, 1):
-        a, b, state, ca, cb = got[rank]
+        a, b, state, ca, cb, ja, jb = got[rank]
+        # every shard call is bracketed by the whole batch's size (5 chains / 3 MSAs) and a reset (pg_engine_set_job_items)
+        assert ja == [5, 0] * 2 and jb == [3, 0] * 2
         assert a == want_a and b == want_b                    # every rank returns the full, identical result
         assert state == want_state                            # and leaves the interpreter RNG where one process would
     assert got[0][3] == [(3, 24)] * 2 and got[1][3] == [(2, 24)] * 2          # contiguous blocks: 3 + 2 chains
