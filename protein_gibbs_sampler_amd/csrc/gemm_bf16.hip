@@ -774,6 +774,10 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   //   128^2             16.4  19.8  26.9   78
   //   256^2 ping-pong         31.4  36.4   87      (wins from >= 128 tiles: 41 vs 49 us at M = 8192)
   if (K % 64) return fail(1, "gemm: K must be a multiple of 64");
+  if (epi == EPI_SPLIT3_GELU) {      // strict-mode fc1: only the 16-wave 256 x 256 kernel has this epilogue
+    if (M % 256 || N % 256 || ldo != 3 * N) return fail(1, "gemm: split-operand epilogue needs M, N multiples of 256 and ldo = 3 N");
+    return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
+  }
   // Deep K with few tiles (fc2 of a few dozen chains: K = 5120, 80-320 tiles): K-splits run side by side into ws, then one
   // reduction adds them to the residual stream in fixed order.  M = 1024: 43 -> 21 us, M = 32: 15.6 -> 8 us.
   if (epi == EPI_F32_RESID && ws && K >= 2048 && M >= 16 && M % 16 == 0 && N % 64 == 0 && variant != 1 && variant < 6) {

@@ -40,8 +40,10 @@ __device__ __forceinline__ float w4_gelu_bf16out(float x) {       // as gelu_bf1
 // instruction).  Per element 1 (abs) + 2.5 + 4 (quarter-rate v_exp_f32) + 0.5 + 1 (max) = 9 issue slots instead of 12; the
 // arithmetic per element is identical (same fma chain), so results do not change.  Packs the pair to bf16.
 typedef __attribute__((ext_vector_type(2))) float pg_f32x2;
-__device__ __forceinline__ uint32_t w4_gelu_bf16out_pack2(float x0, float x1) {
-  const pg_f32x2 x = {x0, x1};
+#ifndef PG_STRICT_GELU_POLY
+#define PG_STRICT_GELU_POLY 1
+#endif
+__device__ __forceinline__ pg_f32x2 w4_gelu_poly2(float x0, float x1) {
   const pg_f32x2 t = {fabsf(x0), fabsf(x1)};
   pg_f32x2 p = {-4.074793151e-04f, -4.074793151e-04f};
   p = __builtin_elementwise_fma(p, t, (pg_f32x2){6.563348950e-03f, 6.563348950e-03f});
@@ -51,8 +53,10 @@ __device__ __forceinline__ uint32_t w4_gelu_bf16out_pack2(float x0, float x1) {
   p = __builtin_elementwise_fma(p, t, (pg_f32x2){-1.000206717e+00f, -1.000206717e+00f});
   const pg_f32x2 e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
   const pg_f32x2 r = {fmaxf(x0, 0.f), fmaxf(x1, 0.f)};
-  const pg_f32x2 g = __builtin_elementwise_fma(-t, e, r);
-  (void)x;
+  return __builtin_elementwise_fma(-t, e, r);
+}
+__device__ __forceinline__ uint32_t w4_gelu_bf16out_pack2(float x0, float x1) {
+  const pg_f32x2 g = w4_gelu_poly2(x0, x1);
   return pack_bf16x2(g[0], g[1]);
 }
 
@@ -98,6 +102,53 @@ __device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, 
       const int row = wave * RB + it * 2 + (lane >> 5);
       const uint4 v = *(const uint4*)(smem + row * 512 + ((c ^ (row & 31)) << 4));
       PG_NT_STORE((uint4*)(ob + (size_t)(it * 2 + (lane >> 5)) * ldo), v);
+    }
+    return;
+  }
+  if (EPI == EPI_SPLIT3_GELU) {
+    // Strict-mode fc1 (16-wave element order only): erf-GELU in registers, the value split into its bf16 (hi, lo) pair, and
+    // the K-concatenated operand rows [lo | hi | hi] of fc2 written straight from here (ldo = 3 N) -- instead of an fp32 tile
+    // plus a separate GELU-and-split pass over it (8 of 14 bytes per element less traffic).  Two halves of 128 token rows
+    // (half h = tile rows with bit 5 == h = elements with bit 1 of e == h), each staged as a hi tile and a lo tile of 64 KB.
+    static_assert(EPI != EPI_SPLIT3_GELU || NW == 16, "element order of the 16-wave kernel");
+    const int nsplit = ldo / 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h) __syncthreads();
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        if (((e >> 1) & 1) != h) continue;
+        int row, n;
+        const f32x4 a = elem(e, row, n);
+        const float4 b4 = *(const float4*)(bias + n0 + n);
+#if PG_STRICT_GELU_POLY
+        const pg_f32x2 ga = w4_gelu_poly2(a[0] + b4.x, a[1] + b4.y), gb = w4_gelu_poly2(a[2] + b4.z, a[3] + b4.w);
+        const float g0 = ga[0], g1 = ga[1], g2 = gb[0], g3 = gb[1];
+#else
+        const float g0 = w4_gelu_erf(a[0] + b4.x), g1 = w4_gelu_erf(a[1] + b4.y), g2 = w4_gelu_erf(a[2] + b4.z), g3 = w4_gelu_erf(a[3] + b4.w);
+#endif
+        uint2 hi, lo;
+        hi.x = pack_bf16x2(g0, g1);
+        hi.y = pack_bf16x2(g2, g3);
+        lo.x = pack_bf16x2(g0 - __uint_as_float(hi.x << 16), g1 - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack_bf16x2(g2 - __uint_as_float(hi.y << 16), g3 - __uint_as_float(hi.y & 0xffff0000u));
+        const int hr = (row >> 6) * 32 + (row & 31);
+        const int off = hr * 512 + (((n >> 3) ^ (hr & 31)) << 4) + (n & 4) * 2;
+        *(uint2*)(smem + off) = hi;
+        *(uint2*)(smem + 65536 + off) = lo;
+      }
+      __syncthreads();
+      const int c = lane & 31;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int hr = wave * 8 + it * 2 + (lane >> 5);
+        const uint4 vh = *(const uint4*)(smem + hr * 512 + ((c ^ (hr & 31)) << 4));
+        const uint4 vl = *(const uint4*)(smem + 65536 + hr * 512 + ((c ^ (hr & 31)) << 4));
+        bf16_t* o = (bf16_t*)out + (size_t)(m0 + (hr >> 5) * 64 + h * 32 + (hr & 31)) * ldo + n0 + c * 8;
+        PG_NT_STORE((uint4*)o, vl);
+        PG_NT_STORE((uint4*)(o + nsplit), vh);
+        PG_NT_STORE((uint4*)(o + 2 * nsplit), vh);
+      }
     }
     return;
   }

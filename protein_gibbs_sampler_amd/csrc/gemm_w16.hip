@@ -171,6 +171,7 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
     PG_W16_CASE(EPI_F32_RESID)
     PG_W16_CASE(EPI_F32)
     PG_W16_CASE(EPI_F32_GELU)
+    PG_W16_CASE(EPI_SPLIT3_GELU)
     default:
       return fail(1, "gemm_w16: bad epilogue");
   }

@@ -11,7 +11,8 @@ namespace pg {
 struct SeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_GELU = 4,
-       EPI_F32_PARTIAL = 5 /* internal: split-K partial sums, no bias */ };
+       EPI_F32_PARTIAL = 5 /* internal: split-K partial sums, no bias */,
+       EPI_SPLIT3_GELU = 6 /* strict mode fc1: erf-GELU, then the bf16 operand rows [lo | hi | hi] (ldo = 3 N) that fc2 reads; 16-wave kernel only */ };
 
 // out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M a multiple of 16 up to 256 rows, of 128 beyond; N a multiple of 64; K of 64
 // (activation buffers are padded to 256 rows: kernels may touch the padding rows of the last tile).
