@@ -205,7 +205,8 @@ int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t*
 /* ---- kernel-level debug entry points (parity tests call individual kernels through these) --- */
 /* out[M][N] = x[M][K] @ w[N][K]^T + bias (fp32 host buffers; computed in `precision`); epi: 0 none, 1 gelu,
  * 2 residual (out is read too: out += x w^T + bias), 3 bf16 output, 4 bf16 output + gelu.  PG_PREC_FP32 (the engine's
- * strict-mode projection: one GEMM over K-concatenated split-bf16 operands) takes epi 0 and 2 */
+ * strict-mode projection: one GEMM over K-concatenated split-bf16 operands) takes epi 0, 2 and 5 = fc1's fused epilogue
+ * (GELU, then the split operand rows fc2 reads; N a multiple of 256; out = hi + lo of those rows) */
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi);
 /* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events; M a multiple of 16,

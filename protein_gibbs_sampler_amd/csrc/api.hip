@@ -433,7 +433,16 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
   PG_HIP(hipMemcpy(dw, w, (size_t)N * K * 4, hipMemcpyHostToDevice));
   PG_HIP(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
   if (precision == PG_PREC_FP32) {
-    if (epi != 0 && epi != 2) return fail(PG_ERR_UNSUPPORTED, "strict mode: plain (0) and residual (2) epilogues only");
+    if (epi == 5) {      // fc1's fused epilogue: operand rows [lo | hi | hi] of gelu(x w^T + b); returned as hi + lo
+      if (N % 256) return fail(PG_ERR_INVALID, "pg_dbg_gemm: the fused GELU-and-split epilogue needs N a multiple of 256");
+      bf16_t* o3 = (bf16_t*)t.get((size_t)Mp * 3 * N * 2);
+      if (!o3) return fail(PG_ERR_HIP, "hipMalloc failed");
+      if ((rc = launch_split3_bf16(nullptr, dx, bx, Mp, K, 1.f, false, false))) return rc;
+      if ((rc = launch_split3_bf16(nullptr, dw, bw, N, K, 1.f, false, true))) return rc;
+      if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, o3, Mp, N, 3 * K, 3 * K, 3 * K, 3 * N, EPI_SPLIT3_GELU))) return rc;
+      return split3_rows_to_host(o3, out, M, N);
+    }
+    if (epi != 0 && epi != 2) return fail(PG_ERR_UNSUPPORTED, "strict mode: plain (0), residual (2) and fused GELU-split (5) epilogues only");
     if ((rc = launch_split3_bf16(nullptr, dx, bx, Mp, K, 1.f, false, false))) return rc;
     if ((rc = launch_split3_bf16(nullptr, dw, bw, N, K, 1.f, false, true))) return rc;
     if (epi == 2) PG_HIP(hipMemcpy(dout, out, (size_t)M * N * 4, hipMemcpyHostToDevice));
