@@ -396,15 +396,16 @@ int dbg_device(int device) {
   PG_HIP(hipSetDevice(device));
   return PG_OK;
 }
-// device rows [lo | hi | hi] (3 d bf16, the strict mode's activation operand) -> host fp32 rows hi + lo; also checks that
-// the two hi copies agree
+// device rows in the strict mode's split operand layout (3 d bf16: per group of 32 columns [lo | hi | hi]) -> host fp32 rows
+// hi + lo; also checks that the two hi copies agree
 int split3_rows_to_host(const bf16_t* c3, float* dst, int64_t M, int d) {
   PG_HIP(hipDeviceSynchronize());
   std::vector<bf16_t> h((size_t)M * 3 * d);
   PG_HIP(hipMemcpy(h.data(), c3, h.size() * 2, hipMemcpyDeviceToHost));
   for (int64_t r = 0; r < M; ++r)
     for (int c = 0; c < d; ++c) {
-      const bf16_t lo = h[(size_t)r * 3 * d + c], hi = h[(size_t)r * 3 * d + d + c], hi2 = h[(size_t)r * 3 * d + 2 * d + c];
+      const size_t g = (size_t)r * 3 * d + (size_t)(c >> 5) * 96 + (c & 31);
+      const bf16_t lo = h[g], hi = h[g + 32], hi2 = h[g + 64];
       if (hi != hi2) return fail(PG_ERR_HIP, "split operand row: the two hi copies differ");
       dst[(size_t)r * d + c] = bf16_to_f32(hi) + bf16_to_f32(lo);
     }

@@ -16,9 +16,9 @@
 
 namespace pg {
 
-// One thread's 64 context values of head h -> bf16 at dst (already offset to the head's columns).  split_d > 0: the row is
-// the strict mode's K-concatenated operand [lo | hi | hi] (3 * split_d wide, elementwise.hip store_row_bf16).
-__device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf16_t* dst, int split_d) {
+// One thread's 64 context values of head h -> bf16 into the token's context row.  split_d > 0: the row is the strict mode's
+// split operand (3 * split_d values, groups of 32 columns [lo | hi | hi]; elementwise.hip store_row_bf16).
+__device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf16_t* row, int h, int split_d) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const float a = o[4 * i] * inv, b = o[4 * i + 1] * inv, c = o[4 * i + 2] * inv, d = o[4 * i + 3] * inv;
@@ -26,17 +26,17 @@ __device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf1
     p.x = pack_bf16x2(a, b);
     p.y = pack_bf16x2(c, d);
     if (!split_d) {
-      ((uint2*)dst)[i] = p;
+      ((uint2*)(row + h * 64))[i] = p;
     } else {
       r.x = pack_bf16x2(a - bf16_to_f32((bf16_t)(p.x & 0xffff)), b - bf16_to_f32((bf16_t)(p.x >> 16)));
       r.y = pack_bf16x2(c - bf16_to_f32((bf16_t)(p.y & 0xffff)), d - bf16_to_f32((bf16_t)(p.y >> 16)));
-      ((uint2*)dst)[i] = r;
-      ((uint2*)(dst + split_d))[i] = p;
-      ((uint2*)(dst + 2 * split_d))[i] = p;
+      bf16_t* g = row + (2 * h + (i >> 3)) * 96 + (i & 7) * 4;       // columns h*64 + 4i .. +3
+      *(uint2*)g = r;
+      *(uint2*)(g + 32) = p;
+      *(uint2*)(g + 64) = p;
     }
   }
 }
-
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -177,8 +177,9 @@ struct SplitAttn {
     }
   }
 
-  // dst = the query's context row at column h*64 + fq*4; bf16, or the strict mode's [lo | hi | hi] operand row
-  static __device__ __forceinline__ void store_ctx(const f32x4 (&o)[4], float l, bf16_t* dst, int split_d) {
+  // row = the query's context row; the lane holds columns h*64 + db*16 + fq*4 .. +3.  bf16, or the strict mode's split operand
+  // row (groups of 32 columns [lo | hi | hi])
+  static __device__ __forceinline__ void store_ctx(const f32x4 (&o)[4], float l, bf16_t* row, int h, int fq, int split_d) {
     const float inv = 1.0f / l;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -187,13 +188,14 @@ struct SplitAttn {
       p.x = pack_bf16x2(a, b);
       p.y = pack_bf16x2(c, d);
       if (!split_d) {
-        *(uint2*)(dst + db * 16) = p;
+        *(uint2*)(row + h * 64 + db * 16 + fq * 4) = p;
       } else {
         r.x = pack_bf16x2(a - __uint_as_float(p.x << 16), b - __uint_as_float(p.x & 0xffff0000u));
         r.y = pack_bf16x2(c - __uint_as_float(p.y << 16), d - __uint_as_float(p.y & 0xffff0000u));
-        *(uint2*)(dst + db * 16) = r;
-        *(uint2*)(dst + split_d + db * 16) = p;
-        *(uint2*)(dst + 2 * split_d + db * 16) = p;
+        bf16_t* g = row + (2 * h + (db >> 1)) * 96 + (db & 1) * 16 + fq * 4;
+        *(uint2*)g = r;
+        *(uint2*)(g + 32) = p;
+        *(uint2*)(g + 64) = p;
       }
     }
   }
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
     A::softmax_pv(st, o, m, l, Vh, Vl, fr, fq);
   }
   const int q = q0 + fr;
-  if (active && q < T) A::store_ctx(o, l, ctx + row0 * ld_ctx_ + (size_t)q * ld_ctx + h * 64 + fq * 4, split_d);
+  if (active && q < T) A::store_ctx(o, l, ctx + row0 * ld_ctx_ + (size_t)q * ld_ctx, h, fq, split_d);
 }
 
 // ---- tied row attention (MSA), step 1: S[b,h][i][j] = scale * sum_r q_r[i] . k_r[j] ---------------------------------
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void msa_row_apply_split_kernel(const float
     __syncthreads();
     if (active) A::softmax_pv(st, o, m, l, Vh, Vl, fr, fq);
   }
-  if (active && q < C) A::store_ctx(o, l, ctx + (((size_t)b * R + r) * C + q) * ld_ctx + h * 64 + fq * 4, split_d);
+  if (active && q < C) A::store_ctx(o, l, ctx + (((size_t)b * R + r) * C + q) * ld_ctx, h, fq, split_d);
 }
 
 __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restrict__ qkv, bf16_t* __restrict__ ctx,
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
     }
     m = mn;
   }
-  if (valid) store_ctx64(o, 1.0f / l, ctx + row0 * ld_ctx_ + (size_t)qi * ld_ctx + h * 64, split_d);
+  if (valid) store_ctx64(o, 1.0f / l, ctx + row0 * ld_ctx_ + (size_t)qi * ld_ctx, h, split_d);
 }
 
 // ---- strict tied row attention (MSA): S = scale * sum_r q_r k_r^T (fp32, to a scratch buffer), then
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(64) void msa_row_apply_f32_kernel(const float* __re
       }
     }
   }
-  if (valid) store_ctx64(o, 1.0f / l, ctx + (((size_t)b * R + r) * C + qi) * ld_ctx + h * 64, split_d);
+  if (valid) store_ctx64(o, 1.0f / l, ctx + (((size_t)b * R + r) * C + qi) * ld_ctx, h, split_d);
 }
 
 static int attn_f32_mode() {

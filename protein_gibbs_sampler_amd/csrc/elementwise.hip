@@ -55,25 +55,29 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[kMaxCh], int nch4, int la
     }
 }
 
-// hi = bf16(v).  split3 (strict precision mode): the row is the K-concatenated split-bf16 activation operand
-// [lo | hi | hi] of 3 * d values with lo = bf16(v - hi); against a weight row packed [hi | lo | hi] one bf16 GEMM over
-// K = 3 d sums  x_lo.w_hi + x_hi.w_lo + x_hi.w_hi  (small terms first) in its fp32 accumulator.
+// hi = bf16(v).  split3 (strict precision mode): the row becomes the split-bf16 activation operand of 3 * d values, interleaved
+// in groups of 32 columns: group g = [lo(32) | hi(32) | hi(32)] of columns 32g .. 32g+31, lo = bf16(v - hi).  Against a weight
+// row packed [hi | lo | hi] the same way, one bf16 GEMM over K' = 3 d sums, per 32 columns and in this order,
+// x_lo.w_hi + x_hi.w_lo + x_hi.w_hi in its fp32 accumulator -- whichever tile kernel runs it; the fused 16-wave kernel
+// (gemm_w16.hip) reads only the first two blocks of each group and issues the same three products from registers.
 __device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane, bool split3 = false) {
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) {
+      const int ci = lane + 64 * i;              // float4 index = columns 4 ci .. 4 ci + 3
       uint2 p;
       p.x = pack_bf16x2(v[i].x, v[i].y);
       p.y = pack_bf16x2(v[i].z, v[i].w);
       if (!split3) {
-        ((uint2*)dst)[lane + 64 * i] = p;
+        ((uint2*)dst)[ci] = p;
       } else {
         uint2 q;
         q.x = pack_bf16x2(v[i].x - bf16_to_f32((bf16_t)(p.x & 0xffff)), v[i].y - bf16_to_f32((bf16_t)(p.x >> 16)));
         q.y = pack_bf16x2(v[i].z - bf16_to_f32((bf16_t)(p.y & 0xffff)), v[i].w - bf16_to_f32((bf16_t)(p.y >> 16)));
-        ((uint2*)dst)[lane + 64 * i] = q;
-        ((uint2*)dst)[nch4 + lane + 64 * i] = p;
-        ((uint2*)dst)[2 * nch4 + lane + 64 * i] = p;
+        uint2* o = (uint2*)dst + (ci >> 3) * 24 + (ci & 7);      // group of 32 columns = 96 values = 24 uint2
+        o[0] = q;
+        o[8] = p;
+        o[16] = p;
       }
     }
 }
@@ -307,7 +311,8 @@ __global__ __launch_bounds__(1024) void lm_tail_small_kernel(const float* __rest
 // ---- strict mode helpers: fp32 -> (hi, lo) bf16 pair, optionally through erf-GELU ----------------
 __device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-// src fp32 [rows][K] -> dst bf16 [rows][3K]: [lo | hi | hi] (activation operand) or, WEIGHT, [hi | lo | hi]
+// src fp32 [rows][K] -> dst bf16 [rows][3K], per group of 32 columns [lo | hi | hi] (activation operand) or, WEIGHT, [hi | lo | hi]
+// (layout: store_row_bf16)
 template <bool GELU, bool WEIGHT>
 __global__ void split3_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4, int k4, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,10 +327,11 @@ __global__ void split3_bf16_kernel(const float* __restrict__ src, bf16_t* __rest
     q.x = pack_bf16x2(v.x - bf16_to_f32((bf16_t)(p.x & 0xffff)), v.y - bf16_to_f32((bf16_t)(p.x >> 16)));
     q.y = pack_bf16x2(v.z - bf16_to_f32((bf16_t)(p.y & 0xffff)), v.w - bf16_to_f32((bf16_t)(p.y >> 16)));
     const int64_t row = i / k4;
-    uint2* o = (uint2*)dst + row * 3 * k4 + (i - row * k4);
+    const int ci = (int)(i - row * k4);
+    uint2* o = (uint2*)dst + row * 3 * k4 + (ci >> 3) * 24 + (ci & 7);
     o[0] = WEIGHT ? p : q;
-    o[k4] = WEIGHT ? q : p;
-    o[2 * k4] = p;
+    o[8] = WEIGHT ? q : p;
+    o[16] = p;
   }
 }
 __global__ void gelu_f32_kernel(float* __restrict__ p, int64_t n) {
@@ -420,7 +426,7 @@ int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const floa
 
 int launch_split3_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t rows, int K, float scale, bool gelu, bool weight) {
   if (rows == 0) return 0;
-  if (K % 4) return fail(1, "split: K must be a multiple of 4");
+  if (K % 32) return fail(1, "split: K must be a multiple of 32");
   const int64_t n4 = rows * (K / 4);
   const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
   if (gelu && !weight) hipLaunchKernelGGL((split3_bf16_kernel<true, false>), dim3(grid), dim3(256), 0, s, src, dst, n4, K / 4, scale);

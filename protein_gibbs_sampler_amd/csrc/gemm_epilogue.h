@@ -107,11 +107,10 @@ __device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, 
   }
   if (EPI == EPI_SPLIT3_GELU) {
     // Strict-mode fc1 (16-wave element order only): erf-GELU in registers, the value split into its bf16 (hi, lo) pair, and
-    // the K-concatenated operand rows [lo | hi | hi] of fc2 written straight from here (ldo = 3 N) -- instead of an fp32 tile
+    // the split operand rows of fc2 ([lo | hi | hi] per 32 columns, ldo = 3 N) written straight from here -- instead of an fp32 tile
     // plus a separate GELU-and-split pass over it (8 of 14 bytes per element less traffic).  Two halves of 128 token rows
     // (half h = tile rows with bit 5 == h = elements with bit 1 of e == h), each staged as a hi tile and a lo tile of 64 KB.
     static_assert(EPI != EPI_SPLIT3_GELU || NW == 16, "element order of the 16-wave kernel");
-    const int nsplit = ldo / 3;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (h) __syncthreads();
@@ -144,10 +143,11 @@ __device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, 
         const int hr = wave * 8 + it * 2 + (lane >> 5);
         const uint4 vh = *(const uint4*)(smem + hr * 512 + ((c ^ (hr & 31)) << 4));
         const uint4 vl = *(const uint4*)(smem + 65536 + hr * 512 + ((c ^ (hr & 31)) << 4));
-        bf16_t* o = (bf16_t*)out + (size_t)(m0 + (hr >> 5) * 64 + h * 32 + (hr & 31)) * ldo + n0 + c * 8;
+        // columns n0 + 8c .. +7 of the token row -> group (n0 + 8c) / 32 of the split operand row, [lo | hi | hi] per 32 columns
+        bf16_t* o = (bf16_t*)out + (size_t)(m0 + (hr >> 5) * 64 + h * 32 + (hr & 31)) * ldo + ((n0 >> 5) + (c >> 2)) * 96 + (c & 3) * 8;
         PG_NT_STORE((uint4*)o, vl);
-        PG_NT_STORE((uint4*)(o + nsplit), vh);
-        PG_NT_STORE((uint4*)(o + 2 * nsplit), vh);
+        PG_NT_STORE((uint4*)(o + 32), vh);
+        PG_NT_STORE((uint4*)(o + 64), vh);
       }
     }
     return;
