@@ -440,14 +440,14 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
       if (!o3) return fail(PG_ERR_HIP, "hipMalloc failed");
       if ((rc = launch_split3_bf16(nullptr, dx, bx, Mp, K, 1.f, false, false))) return rc;
       if ((rc = launch_split3_bf16(nullptr, dw, bw, N, K, 1.f, false, true))) return rc;
-      if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, o3, Mp, N, 3 * K, 3 * K, 3 * K, 3 * N, EPI_SPLIT3_GELU))) return rc;
+      if ((rc = launch_gemm_split3(nullptr, bx, bw, db, o3, Mp, N, K, 3 * N, EPI_SPLIT3_GELU))) return rc;
       return split3_rows_to_host(o3, out, M, N);
     }
     if (epi != 0 && epi != 2) return fail(PG_ERR_UNSUPPORTED, "strict mode: plain (0), residual (2) and fused GELU-split (5) epilogues only");
     if ((rc = launch_split3_bf16(nullptr, dx, bx, Mp, K, 1.f, false, false))) return rc;
     if ((rc = launch_split3_bf16(nullptr, dw, bw, N, K, 1.f, false, true))) return rc;
     if (epi == 2) PG_HIP(hipMemcpy(dout, out, (size_t)M * N * 4, hipMemcpyHostToDevice));
-    if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, Mp, N, 3 * K, 3 * K, 3 * K, N, epi == 2 ? EPI_F32_RESID : EPI_F32))) return rc;
+    if ((rc = launch_gemm_split3(nullptr, bx, bw, db, dout, Mp, N, K, N, epi == 2 ? EPI_F32_RESID : EPI_F32))) return rc;
     PG_HIP(hipDeviceSynchronize());
     PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return PG_OK;
@@ -496,11 +496,18 @@ int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int
   hipEvent_t a, b;
   PG_HIP(hipEventCreate(&a));
   PG_HIP(hipEventCreate(&b));
+  // variant 90: the strict mode's fused three-product kernel on operands of logical depth K / 3 (K = 3 x depth, as the plain
+  // kernels see them), so that "variant 2, K" and "variant 90, K" time the same arithmetic
+  auto launch = [&]() {
+    if (variant == 90) return launch_gemm_split3_w16(nullptr, bx, bw, db, dout, M, N, K / 3, N, epi);
+    return launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant, ws, ws ? ws_bytes : 0);
+  };
+  if (variant == 90 && (K % 96 || (epi != EPI_F32 && epi != EPI_F32_RESID))) return fail(PG_ERR_INVALID, "variant 90: K = 3 x depth, fp32 epilogues");
   for (int i = 0; i < 2; ++i)
-    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant, ws, ws ? ws_bytes : 0))) return rc;
+    if ((rc = launch())) return rc;
   PG_HIP(hipEventRecord(a, nullptr));
   for (int i = 0; i < iters; ++i)
-    if ((rc = launch_gemm_bf16_variant(nullptr, bx, bw, db, dout, M, N, K, K, K, N, epi, variant, ws, ws ? ws_bytes : 0))) return rc;
+    if ((rc = launch())) return rc;
   PG_HIP(hipEventRecord(b, nullptr));
   PG_HIP(hipEventSynchronize(b));
   float ms = 0;

@@ -228,17 +228,12 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
 // strict precision mode GEMM: one bf16 MFMA GEMM over the K-concatenated split operands (engine.h) reproduces an
 // fp32 x fp32 product to ~2^-17 relative (the dropped lo.lo term); fp32 accumulation, small terms first.
 int Engine::dense3(const bf16_t* x3, const DenseW& W, float* out, int Mp, bool accumulate) {
-  const int K3 = 3 * W.K;
-  return timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, x3, W.w, W.b, out, Mp, W.N, K3, K3, K3, W.N, accumulate ? EPI_F32_RESID : EPI_F32); });
+  return timed(PC_GEMM, [&] { return launch_gemm_split3(stream, x3, W.w, W.b, out, Mp, W.N, W.K, W.N, accumulate ? EPI_F32_RESID : EPI_F32); });
 }
 
-// ------------------------------------------------------------------------------------------------
-// ESM-1b forward: tokens[B][T] -> x[B*T][d] (residual stream before emb_layer_norm_after)
-// ------------------------------------------------------------------------------------------------
-// Scratch for the split-K form of a small fc2 GEMM (launch_gemm_bf16 decides whether to use it); nullptr for large M.
-// GEMM height for the B*P selected rows (pruned last layer, LM head).  Up to 48 rows would take the weight-streaming kernel,
-// whose k order differs from the tile kernels': fine for a few chains (its regime), but in a big batch the height is raised
-// to one 64-row tile so that the selected rows of a shard and of the whole batch see the same arithmetic.
+// GEMM height for the B*P selected rows (pruned last layer, LM head) and for a forward of few token rows.  Up to 48 rows would
+// take the weight-streaming kernel, whose k order differs from the tile kernels': fine for a few chains (its regime), but in a
+// big batch the height is raised to one 64-row tile so that a shard and the whole batch see the same arithmetic.
 int Engine::sel_gemm_rows(int64_t n_sel, int64_t Np) const {
   if (n_sel > 256) return (int)Np;
   const int r = round_up((int)n_sel, 16);
@@ -251,9 +246,8 @@ int Engine::sel_gemm_rows(int64_t n_sel, int64_t Np) const {
 // split products at |x| ~ 1; 9 instead of 22 issue slots per element in an epilogue that nothing overlaps), the pass with erff.
 // Full-size strict logits against the oracle with this: ESM-1b 5.8e-4, MSA-1b 4.6e-4 (5.7e-4 / 4.0e-4 with erff).
 int Engine::dense3_gelu(const bf16_t* x3, const DenseW& W, int Mp) {
-  const int K3 = 3 * W.K;
   if (W.N % 256 == 0 && Mp % 256 == 0)
-    return timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, x3, W.w, W.b, ffn.as<bf16_t>(), Mp, W.N, K3, K3, K3, 3 * W.N, EPI_SPLIT3_GELU); });
+    return timed(PC_GEMM, [&] { return launch_gemm_split3(stream, x3, W.w, W.b, ffn.as<bf16_t>(), Mp, W.N, W.K, 3 * W.N, EPI_SPLIT3_GELU); });
   int rc = dense3(x3, W, ffn_f32.as<float>(), Mp, false);
   if (rc) return rc;
   return timed(PC_LN, [&] { return launch_split3_bf16(stream, ffn_f32.as<float>(), ffn.as<bf16_t>(), Mp, W.N, 1.f, true, false); });

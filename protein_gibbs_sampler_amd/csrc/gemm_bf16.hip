@@ -765,6 +765,19 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   return launch_gemm_bf16_variant(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant, ws, ws_bytes);
 }
 
+// Strict-mode projection on split operands (X3 [M][3K], W3 [N][3K]; K = logical depth): the fused three-product kernel when its
+// 256 x 256 tiles fill the chip, else the plain GEMM over K' = 3K -- same summation order, bit-identical results
+// (PGIBBS_SPLIT3_FUSED=0 forces the plain form; tests compare the two).
+int launch_gemm_split3(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K, int ldo,
+                       int epi) {
+  static const int fused = [] { const char* e = getenv("PGIBBS_SPLIT3_FUSED"); return e ? atoi(e) : 1; }();
+  const bool ok256 = M % 256 == 0 && N % 256 == 0 && K % 32 == 0;
+  if (ok256 && (epi == EPI_SPLIT3_GELU || (fused && (long)(M / 256) * (N / 256) >= 128)))
+    return launch_gemm_split3_w16(s, X3, W3, bias, out, M, N, K, ldo, epi);
+  if (epi == EPI_SPLIT3_GELU) return fail(1, "gemm: split-operand epilogue needs M, N multiples of 256");
+  return launch_gemm_bf16(s, X3, W3, bias, out, M, N, 3 * K, 3 * K, 3 * K, ldo, epi);
+}
+
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws, size_t ws_bytes) {
   // Dispatch by how many tiles each kernel would put on the 256 CUs (times in us, tools/gemm_mid_bench.py, N=1280 K=1280):
@@ -774,10 +787,6 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   //   128^2             16.4  19.8  26.9   78
   //   256^2 ping-pong         31.4  36.4   87      (wins from >= 128 tiles: 41 vs 49 us at M = 8192)
   if (K % 64) return fail(1, "gemm: K must be a multiple of 64");
-  if (epi == EPI_SPLIT3_GELU) {      // strict-mode fc1: only the 16-wave 256 x 256 kernel has this epilogue
-    if (M % 256 || N % 256 || ldo != 3 * N) return fail(1, "gemm: split-operand epilogue needs M, N multiples of 256 and ldo = 3 N");
-    return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
-  }
   // Deep K with few tiles (fc2 of a few dozen chains: K = 5120, 80-320 tiles): K-splits run side by side into ws, then one
   // reduction adds them to the residual stream in fixed order.  M = 1024: 43 -> 21 us, M = 32: 15.6 -> 8 us.
   if (epi == EPI_F32_RESID && ws && K >= 2048 && M >= 16 && M % 16 == 0 && N % 64 == 0 && variant != 1 && variant < 6) {

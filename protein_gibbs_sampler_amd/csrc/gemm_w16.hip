@@ -134,6 +134,142 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
   w4_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Strict precision mode: the three split-bf16 products of a projection from ONE pass over the operands.
+//   X3 [M][3K], W3 [N][3K]: per group of 32 columns X3 = [xl | xh | xh], W3 = [wh | wl | wh] (elementwise.hip store_row_bf16).
+// A "K-step" here is one group: the first 64 values (128 B) of the group from each operand row -- xl, xh / wh, wl of 32
+// columns -- land in the same 128-B LDS rows as a plain K-step of 64, so the DMA pieces, the swizzle and the fragment
+// addressing are those of gemm_bf16_w16_kernel (half 0 of a row = xl / wh, half 1 = xh / wl); only the source stride per
+// step (192 B instead of 128) and the MFMA list differ:   acc += wh.xl ; acc += wl.xh ; acc += wh.xh   (48 MFMAs per 64 KB
+// staged instead of 32: the operand feed, not the matrix pipe, bounds these kernels).  Per accumulator that is exactly the
+// sequence a plain bf16 GEMM over K' = 3K walks through on this layout -- the k order of every other tile kernel -- so the
+// result is bit-identical with launch_gemm_bf16 on the same operands (tests/test_gpu_strict_kernels.py), and a batch split
+// into shards that pick different kernels still computes the same logits.
+template <int EPI, int GM>
+__global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                                 const float* __restrict__ bias, void* __restrict__ out, int K,
+                                                                 int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * W16_KSLOT];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = n_tiles >> 3, r = n_tiles & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int tile_m, tile_n;
+  {
+    const int tiles_m = n_tiles / tiles_n;
+    const int gsz = GM * tiles_n, g = bid / gsz, within = bid - g * gsz;
+    const int rows = (tiles_m - g * GM) < GM ? (tiles_m - g * GM) : GM;
+    tile_m = g * GM + within % rows;
+    tile_n = within / rows;
+  }
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  // K = logical depth (columns of the unsplit operand); ldx, ldw = 3K-wide rows
+  const bool stage_w = wave >= 8;
+  const int ld_ = stage_w ? ldw : ldx;
+  const bf16_t* src = (stage_w ? W + (size_t)n0 * ldw : X + (size_t)m0 * ldx) + (size_t)(wave & 7) * 32 * ld_;
+  const rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (31 * ld_ + 3 * K) * 2, 0x00020000);
+  const int dma_voff = ((lane >> 3) * ld_ + ((lane & 7) ^ (lane >> 3)) * 8) * 2;
+  const int piece_bytes = 8 * ld_ * 2;
+  const int lds_piece0 = wave * 4 * 1024;
+  const int nk = K / 32;                             // groups of 32 columns
+
+  auto dma_step = [&](int t) {
+    char* dst = smem + (t & 1) * W16_KSLOT + lds_piece0;
+    const int soff = t < nk ? t * 192 : 0x7f000000;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, PG_LDS_PTR(dst + g * 1024), 16, dma_voff, soff + g * piece_bytes, 0, 0);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int foff0 = fr * 128 + ((fq ^ (fr & 7)) << 4);            // xl / wh: chunks 0-3 of the row
+  const int foff1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);      // xh / wl: chunks 4-7
+  const int xbase = wm * 4 * 2048;
+  const int wbase = 32 * 1024 + wn * 4 * 2048;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_step(0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    dma_step(t + 1);
+    const char* sb = smem + (t & 1) * W16_KSLOT;
+    bf16x8 xl[4], xh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xl[j] = *(const bf16x8*)(sb + xbase + j * 2048 + foff0);
+      xh[j] = *(const bf16x8*)(sb + xbase + j * 2048 + foff1);
+    }
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip) {                 // two W row blocks at a time: 48 fragment registers live, not 64
+      bf16x8 wh[2], wl[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        wh[u] = *(const bf16x8*)(sb + wbase + (ip * 2 + u) * 2048 + foff0);
+        wl[u] = *(const bf16x8*)(sb + wbase + (ip * 2 + u) * 2048 + foff1);
+      }
+      // per accumulator: wh.xl, then wl.xh, then wh.xh -- three sweeps over the 8 accumulators, so no MFMA follows its producer
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[u], xl[j], acc[ip * 2 + u][j], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[u], xh[j], acc[ip * 2 + u][j], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[u], xh[j], acc[ip * 2 + u][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  auto elem = [&](int e, int& m_loc, int& n_loc) -> f32x4 {
+    m_loc = wm * 64 + (e & 3) * 16 + fr;
+    n_loc = wn * 64 + (e >> 2) * 16 + fq * 4;
+    return acc[e >> 2][e & 3];
+  };
+  w4_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
+}
+
+// X3 [M][3K], W3 [N][3K] in the split operand layout; K = logical depth (a multiple of 32); M, N multiples of 256.
+// epi: EPI_F32, EPI_F32_RESID or EPI_SPLIT3_GELU.
+int launch_gemm_split3_w16(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K,
+                           int ldo, int epi) {
+  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+  if (M % 256 || N % 256 || K % 32 || K < 32 || n_tiles < 1) return fail(1, "gemm_split3_w16: shape");
+  const int gm = K >= 4096 ? 2 : 4;
+  dim3 grid(n_tiles), block(1024);
+#define PG_S3_CASE(E)                                                                                                          \
+  case E:                                                                                                                      \
+    if (gm == 2) hipLaunchKernelGGL((gemm_split3_w16_kernel<E, 2>), grid, block, 0, s, X3, W3, bias, out, K, 3 * K, 3 * K, ldo, tiles_n, n_tiles); \
+    else hipLaunchKernelGGL((gemm_split3_w16_kernel<E, 4>), grid, block, 0, s, X3, W3, bias, out, K, 3 * K, 3 * K, ldo, tiles_n, n_tiles);     \
+    break;
+  switch (epi) {
+    PG_S3_CASE(EPI_F32)
+    PG_S3_CASE(EPI_F32_RESID)
+    PG_S3_CASE(EPI_SPLIT3_GELU)
+    default:
+      return fail(1, "gemm_split3_w16: bad epilogue");
+  }
+#undef PG_S3_CASE
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int ABL>
 static int launch_w16_abl(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int K, int ldx, int ldw,
                           int ldo, int tiles_n, int n_tiles) {
@@ -171,7 +307,6 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
     PG_W16_CASE(EPI_F32_RESID)
     PG_W16_CASE(EPI_F32)
     PG_W16_CASE(EPI_F32_GELU)
-    PG_W16_CASE(EPI_SPLIT3_GELU)
     default:
       return fail(1, "gemm_w16: bad epilogue");
   }

@@ -32,6 +32,12 @@ int launch_gemm_w4(hipStream_t s, const bf16_t* X, const bf16_t* W, const float*
 // the 16-wave 256x256 tile kernel (gemm_w16.hip): same contract
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                     int ldw, int ldo, int epi, int abl = 0);
+// strict mode: the three split-bf16 products of a projection in one pass (gemm_w16.hip); X3 / W3 in the split operand layout,
+// K = logical depth; bit-identical with launch_gemm_bf16 over K' = 3K on the same operands
+int launch_gemm_split3(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K, int ldo,
+                       int epi);      // dispatcher: fused kernel or the plain GEMM over K' = 3K (gemm_bf16.hip)
+int launch_gemm_split3_w16(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K,
+                           int ldo, int epi);
 
 // fused attention, one (sequence, head) per workgroup; qkv rows are [q | k | v] with head h at h*64
 // key_tok (optional): the int32 token buffer [n_seq][T]; keys whose token is pad_idx are masked (ragged batches)

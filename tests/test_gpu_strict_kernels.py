@@ -61,6 +61,39 @@ def test_strict_fc1_fused_gelu_split_epilogue(M, N, K):
     assert err < 3e-5 * max(1.0, np.abs(z).max()), err
 
 
+_FUSED_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import _lib
+outs = []
+for M, N, K, epi in ((8448, 1280, 320, 0), (8448 + 256, 1280, 128, 2), (16384, 2304, 64, 0)):
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
+    b = rng.standard_normal(N, dtype=np.float32)
+    out = rng.standard_normal((M, N), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_FP32, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
+    outs.append(out)
+np.savez(sys.argv[1], *outs)
+"""
+
+
+def test_fused_three_product_kernel_is_bit_identical_with_the_plain_gemm(tmp_path):
+    """Shapes with >= 128 tiles of 256 x 256 take gemm_split3_w16_kernel (three MFMA products per staged operand block); with
+    PGIBBS_SPLIT3_FUSED=0 the same operands go through the plain bf16 GEMM over K' = 3K.  Same k order per accumulator ->
+    the outputs must be equal bit for bit (this is what keeps strict-mode shards of any size identical)."""
+    res = {}
+    for fused in ("1", "0"):
+        f = str(tmp_path / ("fused%s.npz" % fused))
+        env = dict(os.environ, PGIBBS_SPLIT3_FUSED=fused)
+        p = subprocess.run([sys.executable, "-c", _FUSED_CHILD % ROOT, f], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        res[fused] = np.load(f)
+    for k in res["1"].files:
+        assert (res["1"][k] == res["0"][k]).all(), k
+
+
 def _attention_ref(qkv, d, H):
     B, T = qkv.shape[:2]
     r = qkv.astype(np.float64)
