@@ -29,6 +29,20 @@ namespace pg {
 
 constexpr int W16_KSLOT = 64 * 1024;
 
+// tools/probes/gemm_clock.hip: shader-clock and 100 MHz wall-clock stamps around the main loop (compiled out of the library)
+#ifdef PG_W16_PROF
+__device__ unsigned long long* pg_w16_prof;      // [workgroup][4]: shader clock / wall clock at loop entry and exit
+#define PG_W16_T(i)                                                                                   \
+  do {                                                                                                \
+    if (threadIdx.x == 0) {                                                                           \
+      pg_w16_prof[(size_t)blockIdx.x * 4 + (i)] = __builtin_readcyclecounter();                       \
+      pg_w16_prof[(size_t)blockIdx.x * 4 + (i) + 1] = __builtin_amdgcn_s_memrealtime();               \
+    }                                                                                                 \
+  } while (0)
+#else
+#define PG_W16_T(i)
+#endif
+
 // ABL (micro-benchmark ablations): 0 real kernel; 1 no LDS-DMA in the loop (slot 0 reused); 2 no MFMA; 4 no epilogue;
 // 5 no barrier (timing only); 10 DMA never waited for (timing only)
 template <int EPI, int GM, int ABL>
@@ -90,6 +104,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   dma_step(0);
+  PG_W16_T(0);
   for (int t = 0; t < nk; ++t) {
     if ((ABL != 1 && ABL != 10) || t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of K-step t have landed
     __builtin_amdgcn_sched_barrier(0);
@@ -117,6 +132,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the trailing zero-fill pieces, before the LDS is reused
+  PG_W16_T(2);
 
   if (ABL == 4) {
 #pragma unroll
