@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "gemm_w16.hip"
 
@@ -15,7 +16,8 @@ namespace pg {
 int fail(int code, const std::string& msg) { fprintf(stderr, "%s\n", msg.c_str()); return code; }
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool zeros = argc > 1 && argv[1][0] == 'z';      // all-zero operands: same instructions, (almost) no datapath toggling
   const int M = 66048, N = 3840, K = 1280;
   pg::bf16_t *x, *w, *out;
   float* bias;
@@ -27,8 +29,10 @@ int main() {
   std::vector<pg::bf16_t> h((size_t)M * K);
   unsigned st = 1;
   for (auto& v : h) { st = st * 1664525u + 1013904223u; v = pg::f32_to_bf16(((st >> 8) * (1.0f / 8388608.0f) - 1.0f)); }
+  if (zeros) std::fill(h.begin(), h.end(), (pg::bf16_t)0);
   (void)hipMemcpy(x, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   (void)hipMemcpy(w, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+  printf("operands: %s\n", zeros ? "all zero" : "uniform random in [-1, 1)");
   const int n_tiles = (M / 256) * (N / 256);
   unsigned long long* prof;
   (void)hipMalloc(&prof, (size_t)n_tiles * 4 * 8);
