@@ -368,7 +368,10 @@ def main():
                                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                                "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated; %s), avg over the per-layer "
                                                "GEMMs; algorithmic minimum 0.63 GB/launch" % traffic_src,
-                               "avg_launch_ms": ms / launches, "flops_per_launch": gf / launches}
+                               "avg_launch_ms": ms / launches, "flops_per_launch": gf / launches,
+                               "peak_note": "peak = dense bf16 MFMA rate at 2.4 GHz; under this load the shader clock measured inside "
+                                            "the GEMM main loop is ~1.72 GHz (power limit: 2.29 GHz with all-zero operands), "
+                                            "profiles/r02_gemm_clock_probe.txt"}
         if rank == 0:
             out["time_split_ms_per_iter"] = {c: v[0] / n_prof for c, v in parts.items()}
 
