@@ -205,6 +205,18 @@ def test_config4_full_size_msa_gibbs_properties():
     assert (lm.forward_logits(start[:8]) == full[:8]).all() and (lm.forward_logits(start[8:16]) == full[8:16]).all()
 
 
+def test_strict_mode_shards_reproduce_the_single_gpu_gibbs_run():
+    """The strict precision mode (PG_PREC_FP32), 64 chains whole vs 8 shards of 8: the whole batch runs every projection on the fused
+    three-product kernel, an 8-chain shard takes the plain GEMM over K' = 3K for its 45-tile out-proj / fc2 -- same k order, same
+    bits, so the logits of every draw and the tokens are identical."""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wrapper = models.ESM1b(state_dict=weights.synthetic_state_dict(dict(weights.ESM1B_CONFIG), seed=0),
+                               config=dict(weights.ESM1B_CONFIG), precision="fp32")
+    s = esm_sampler.ESM_sampler(wrapper, device="cuda:0")
+    _sharded_gibbs(s, 64, 25, 2, (8,), job_items=True)
+
+
 @pytest.mark.parametrize("B,R,L,P,worlds", [(8, 8, 100, 3, (8, 2)), (4, 16, 256, 5, (4,)), (16, 32, 256, 25, (16,))])
 def test_msa_shards_reproduce_the_single_gpu_gibbs_run(B, R, L, P, worlds):
     """ESM-MSA-1b at full size: B MSAs whole vs contiguous shards that know the job's size -- tokens and the logits of every draw
