@@ -76,7 +76,10 @@ typedef struct pg_engine pg_engine;
 #define PG_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream (throughput mode) */
 #define PG_PREC_FP32 1 /* strict parity mode: every matrix product (projections, q.k^T, P.v) as three bf16 MFMA products on
                           (hi, lo) splits of both operands (lo.hi + hi.lo + hi.hi, fp32 accumulate); fp32 softmax, LayerNorm
-                          and residual stream; ~3x slower, logits within 1e-3 of the fp32 oracle */
+                          and residual stream; ~3x slower, logits within 1e-3 of the fp32 oracle.  The FFN's GELU is
+                          evaluated as relu(x) - |x| 2^p(|x|) with a degree-5 fit p of log2 Phi(-t) (max abs error 3.2e-6,
+                          below the split products' own ~2^-17 relative error) when d_ffn is a multiple of 256 -- both
+                          models -- and with erff otherwise */
 
 typedef struct {
   int32_t arch;
@@ -113,6 +116,9 @@ int pg_engine_device(const pg_engine*);
  * what a single engine computes on the whole batch (jobs with more than 2048 token rows; smaller jobs run in the few-chain
  * regime whose kernels are picked by the local shape).  No effect on results of a call that is a whole job. */
 int pg_engine_set_job_items(pg_engine*, int64_t job_items);
+/* engine counters: "graph_captures" / "graph_replays" = hipGraph captures and replayed iterations of the launch-bound
+ * (few-token) Gibbs loop, which replays ONE captured iteration for every call of the same shape (tests assert the path taken) */
+int pg_engine_get_stat(pg_engine*, const char* name, int64_t* value);
 
 /* Sampling parameters == the kwargs of generate() that reach generate_step
  * (src/pgen/esm_sampler.py:8-45, 227-232). */
@@ -166,6 +172,17 @@ int pg_msa_gibbs_run_device(pg_engine*, int32_t* d_tokens_inout, int B, int R, i
 int pg_msa_gibbs_single_run(pg_engine*, int32_t* tokens_inout, int R, int C, int mask_row, int target_row,
                             const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
                             const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
+/* pg_msa_gibbs_single_batch_run: B calls of generate_single on B MSAs ("templates") of equal shape R x C in ONE pass -- the inner
+ *   loop of pgen_msa_revised (src/pgen/pgen_msa_revised.py:107-115: one generate_single per template and per requested sequence;
+ *   BASELINE config 5 "batch=32 templates").  tokens[B][R][C]; step_idx[n_steps][B][P_max] (template b's partition of ITS OWN
+ *   shuffled positions, < 0 = padding); step_sample_flag[n_steps] (shared: same passes / burn_in); params[B] -- template b draws
+ *   with params[b] (the reference draws one torch seed per call), Philox row id = params[b].row_id_base.
+ *   sampled_logits[n_steps][B][P_max][V], sampled_tokens[n_steps][B][P_max] optional.
+ *   Template b's result is bit-identical with pg_msa_gibbs_single_run on it alone (kernel choices that change a summation order
+ *   are taken per template), hence independent of how templates are batched or sharded over GPUs. */
+int pg_msa_gibbs_single_batch_run(pg_engine*, int32_t* tokens_inout, int B, int R, int C, int mask_row, int target_row,
+                                  const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
+                                  const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
 
 /* ---- masked log-likelihood scoring ----------------------------------------------------------------
  * The forward + log_softmax + gather of log_likelihood_batch (src/pgen/esm_sampler.py:336-348,355-362;

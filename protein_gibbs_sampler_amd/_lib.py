@@ -72,6 +72,7 @@ SIGNATURES = [
     ("pg_engine_synchronize", c_int, [c_void_p]),
     ("pg_engine_device", c_int, [c_void_p]),
     ("pg_engine_set_job_items", c_int, [c_void_p, c_int64]),
+    ("pg_engine_get_stat", c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
     ("pg_esm_forward_logits", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     ("pg_esm_gibbs_run", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(SampleParams), c_void_p,
                                  c_void_p]),
@@ -84,6 +85,8 @@ SIGNATURES = [
                                         c_void_p, c_void_p]),
     ("pg_msa_gibbs_single_run", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                         POINTER(SampleParams), c_void_p, c_void_p]),
+    ("pg_msa_gibbs_single_batch_run", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                              c_int, POINTER(SampleParams), c_void_p, c_void_p]),
     ("pg_esm_forward_logprobs", c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     ("pg_msa_forward_logprobs", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_void_p]),

@@ -98,6 +98,14 @@ int pg_engine_set_job_items(pg_engine* h, int64_t job_items) {
   return PG_OK;
 }
 
+int pg_engine_get_stat(pg_engine* h, const char* name, int64_t* value) {
+  if (!h || !name || !value) return fail(PG_ERR_INVALID, "pg_engine_get_stat: null argument");
+  if (!strcmp(name, "graph_captures")) *value = h->e.stat_graph_captures;
+  else if (!strcmp(name, "graph_replays")) *value = h->e.stat_graph_replays;
+  else return fail(PG_ERR_INVALID, std::string("unknown stat ") + name);
+  return PG_OK;
+}
+
 // ---- ESM-1b ---------------------------------------------------------------------------------
 int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, float* logits_out) {
   if (!h || !tokens || !logits_out) return fail(PG_ERR_INVALID, "pg_esm_forward_logits: null argument");
@@ -218,26 +226,29 @@ int pg_msa_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int R, int C, c
   return PG_OK;
 }
 
-int pg_msa_gibbs_single_run(pg_engine* h, int32_t* tokens_inout, int R, int C, int mask_row, int target_row,
-                            const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
-                            const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
+int pg_msa_gibbs_single_batch_run(pg_engine* h, int32_t* tokens_inout, int B, int R, int C, int mask_row, int target_row,
+                                  const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
+                                  const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
   if (!h || !tokens_inout || (n_steps > 0 && (!step_sample_flag || (!step_idx && P_max > 0))))
-    return fail(PG_ERR_INVALID, "pg_msa_gibbs_single_run: null argument");
-  int rc = check_params(params);
-  if (rc) return rc;
-  if (R < 1 || C < 1 || P_max < 0 || n_steps < 0) return fail(PG_ERR_INVALID, "bad shape");
+    return fail(PG_ERR_INVALID, "pg_msa_gibbs_single_batch_run: null argument");
+  if (B < 0 || R < 1 || C < 1 || P_max < 0 || n_steps < 0) return fail(PG_ERR_INVALID, "bad shape");
+  if (B == 0) return PG_OK;
+  int rc;
+  if (!params) return fail(PG_ERR_INVALID, "null pg_sample_params");
+  for (int b = 0; b < B; ++b)
+    if ((rc = check_params(params + b))) return rc;
   Engine& e = h->e;
   DeviceGuard g(e.device);
-  const size_t tok_bytes = (size_t)R * C * 4;
-  const size_t n_draws = (size_t)P_max * n_steps;
-  if (n_draws && (rc = check_idx_table(step_idx, n_draws, C, "pg_msa_gibbs_single_run"))) return rc;
+  const size_t tok_bytes = (size_t)B * R * C * 4;
+  const size_t n_draws = (size_t)B * P_max * n_steps;
+  if (n_draws && (rc = check_idx_table(step_idx, n_draws, C, "pg_msa_gibbs_single_batch_run"))) return rc;
   if ((rc = e.d_tokens.ensure(tok_bytes, e.stream))) return rc;
   if ((rc = e.d_idx.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
   if (sampled_logits && (rc = e.d_samp_logits.ensure((n_draws ? n_draws : 1) * e.cfg.vocab * 4, e.stream))) return rc;
   if (sampled_tokens && (rc = e.d_samp_tok.ensure((n_draws ? n_draws : 1) * 4, e.stream))) return rc;
   PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens_inout, tok_bytes, hipMemcpyHostToDevice, e.stream));
   if (n_draws) PG_HIP(hipMemcpyAsync(e.d_idx.p, step_idx, n_draws * 4, hipMemcpyHostToDevice, e.stream));
-  rc = e.msa_single_device(e.d_tokens.as<int32_t>(), R, C, mask_row, target_row, e.d_idx.as<int32_t>(), step_sample_flag,
+  rc = e.msa_single_device(e.d_tokens.as<int32_t>(), B, R, C, mask_row, target_row, e.d_idx.as<int32_t>(), step_sample_flag,
                            n_steps, P_max, params, sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
                            sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
   if (rc) return rc;
@@ -248,6 +259,16 @@ int pg_msa_gibbs_single_run(pg_engine* h, int32_t* tokens_inout, int R, int C, i
     PG_HIP(hipMemcpyAsync(sampled_tokens, e.d_samp_tok.p, n_draws * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
   return PG_OK;
+}
+
+// generate_single == the batched form with one template
+int pg_msa_gibbs_single_run(pg_engine* h, int32_t* tokens_inout, int R, int C, int mask_row, int target_row,
+                            const int32_t* step_idx, const int32_t* step_sample_flag, int n_steps, int P_max,
+                            const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
+  if (!h || !tokens_inout || (n_steps > 0 && (!step_sample_flag || (!step_idx && P_max > 0))))
+    return fail(PG_ERR_INVALID, "pg_msa_gibbs_single_run: null argument");
+  return pg_msa_gibbs_single_batch_run(h, tokens_inout, 1, R, C, mask_row, target_row, step_idx, step_sample_flag, n_steps, P_max,
+                                       params, sampled_logits, sampled_tokens);
 }
 
 int pg_msa_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int R, int C, const int32_t* d_target_idx,

@@ -180,7 +180,7 @@ struct SplitAttn {
   // row = the query's context row; the lane holds columns h*64 + db*16 + fq*4 .. +3.  bf16, or the strict mode's split operand
   // row (groups of 32 columns [lo | hi | hi])
   static __device__ __forceinline__ void store_ctx(const f32x4 (&o)[4], float l, bf16_t* row, int h, int fq, int split_d) {
-    const float inv = 1.0f / l;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;     // every key masked (an all-<pad> sequence): zero context, not NaN
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       const float a = o[db][0] * inv, b = o[db][1] * inv, c = o[db][2] * inv, d = o[db][3] * inv;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64) void attention_f32_kernel(const float* __restri
     }
     m = mn;
   }
-  if (valid) store_ctx64(o, 1.0f / l, ctx + row0 * ld_ctx_ + (size_t)qi * ld_ctx, h, split_d);
+  if (valid) store_ctx64(o, l > 0.f ? 1.0f / l : 0.f, ctx + row0 * ld_ctx_ + (size_t)qi * ld_ctx, h, split_d);
 }
 
 // ---- strict tied row attention (MSA): S = scale * sum_r q_r k_r^T (fp32, to a scratch buffer), then
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) void msa_row_apply_f32_kernel(const float* __re
       }
     }
   }
-  if (valid) store_ctx64(o, 1.0f / l, ctx + (((size_t)b * R + r) * C + qi) * ld_ctx, h, split_d);
+  if (valid) store_ctx64(o, l > 0.f ? 1.0f / l : 0.f, ctx + (((size_t)b * R + r) * C + qi) * ld_ctx, h, split_d);
 }
 
 static int attn_f32_mode() {

@@ -64,11 +64,13 @@ struct Engine {
   // workspace (grow-only)
   DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
+  DevBuf tmp_idx, tmp_out;                 // batched generate_single on small MSAs: one template's step table / outputs
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask
   float* splitk_ws(int rows, int n, int64_t batch_rows);
   int64_t job_items = 0;                   // pg_engine_set_job_items: batch items of the whole (multi-GPU) job, 0 = this call
-  int64_t job_batch(int64_t B) const { return job_items > B ? job_items : B; }
+  int64_t order_items = 0;                 // > 0: order-changing kernel choices as for a job of this many items (batched generate_single: 1)
+  int64_t job_batch(int64_t B) const { return order_items > 0 ? order_items : (job_items > B ? job_items : B); }
   int64_t batch_rows = 0;                  // token rows of the JOB's forward (job_batch(B) x rows per item; set by the trunks)
   int sel_gemm_rows(int64_t n_sel, int64_t Np) const;
   // launch-bound (small) Gibbs loops: one iteration captured as a hipGraph and replayed; the iteration number lives in
@@ -76,6 +78,7 @@ struct Engine {
   DevBuf d_iter;
   hipGraphExec_t graph_exec = nullptr;
   std::vector<uint8_t> graph_key;
+  int64_t stat_graph_captures = 0, stat_graph_replays = 0;     // pg_engine_get_stat
   // strict precision mode (PG_PREC_FP32): h, ctx, ffn, sel_h hold [lo | hi | hi] rows (3x wide); fp32 fc1 output;
   // row-attention scores (also the bf16 mode's wide-alignment fallback)
   DevBuf ffn_f32, scores;
@@ -105,8 +108,9 @@ struct Engine {
                 int P = 0, int64_t n_sel = 0);
   int msa_gibbs_device(int32_t* d_tok, int B, int R, int C, const int32_t* d_idx, int n_iters, int P,
                        const pg_sample_params* sp, float* d_samp_logits, int32_t* d_samp_tok);
-  // generate_single: B = 1; step s masks row mask_row and samples row target_row at d_step_idx[s][P_max]
-  int msa_single_device(int32_t* d_tok, int R, int C, int mask_row, int target_row, const int32_t* d_step_idx,
+  // generate_single on B templates of equal shape: step s masks row mask_row of every template and samples row target_row of
+  // template b at d_step_idx[s][b][P_max] with sp[b]
+  int msa_single_device(int32_t* d_tok, int B, int R, int C, int mask_row, int target_row, const int32_t* d_step_idx,
                         const int32_t* step_sample_flag_host, int n_steps, int P_max, const pg_sample_params* sp,
                         float* d_samp_logits, int32_t* d_samp_tok);
 

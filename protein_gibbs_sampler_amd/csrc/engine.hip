@@ -92,7 +92,7 @@ Engine::~Engine() {
   if (device >= 0) (void)hipSetDevice(device);
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
-                    &d_rowmap, &scratch, &d_iter, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
+                    &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
   for (DevBuf* b : bufs) b->release();
   prof.destroy();
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -248,8 +248,8 @@ int Engine::sel_gemm_rows(int64_t n_sel, int64_t Np) const {
 int Engine::dense3_gelu(const bf16_t* x3, const DenseW& W, int Mp) {
   if (W.N % 256 == 0 && Mp % 256 == 0)
     return timed(PC_GEMM, [&] { return launch_gemm_split3(stream, x3, W.w, W.b, ffn.as<bf16_t>(), Mp, W.N, W.K, 3 * W.N, EPI_SPLIT3_GELU); });
-  int rc = dense3(x3, W, ffn_f32.as<float>(), Mp, false);
-  if (rc) return rc;
+  int rc = ffn_f32.ensure((size_t)Mp * W.N * 4, stream);       // fp32 intermediate of the unfused form only
+  if (rc || (rc = dense3(x3, W, ffn_f32.as<float>(), Mp, false))) return rc;
   return timed(PC_LN, [&] { return launch_split3_bf16(stream, ffn_f32.as<float>(), ffn.as<bf16_t>(), Mp, W.N, 1.f, true, false); });
 }
 
@@ -277,7 +277,6 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     if ((rc = qkv.ensure((size_t)Mp * 3 * d * 4, stream))) return rc;
     if ((rc = ctx.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;
     if ((rc = ffn.ensure((size_t)Mp * 3 * f * 2, stream))) return rc;
-    if ((rc = ffn_f32.ensure((size_t)Mp * f * 4, stream))) return rc;
     float* X = x.as<float>();
     float* QKVf = qkv.as<float>();
     const float eps = cfg.layer_norm_eps;
@@ -413,25 +412,35 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
 
   // Launch-bound regime (few tokens: ~270 launches of a few microseconds each): capture ONE iteration as a hipGraph and
   // replay it.  Needs the pruned path (no per-iteration pointers besides the idx table), no per-iteration outputs, no
-  // event profiling.  Iteration 0 runs eagerly (it sizes every workspace buffer: no allocation inside the capture).
-  const bool graphable = use_graph && pruned && !prof.on && !d_samp_logits_ && !d_samp_tok_ && n_iters >= 3 &&
-                         (int64_t)B * T <= 4096;
-  if (!graphable) {
+  // event profiling.  The iteration number and the sampling parameters (seed, burn-in, top-k ...) live in a device-side state
+  // block, so the SAME graph is replayed by every later call of the same shape on the same buffers -- a generate() per
+  // sequence (BASELINE config 1) captures once, not once per call.  Before a capture iteration 0 runs eagerly (it sizes every
+  // workspace buffer: no allocation inside the capture).
+  const bool graphable = use_graph && pruned && !prof.on && !d_samp_logits_ && !d_samp_tok_ && (int64_t)B * T <= 4096;
+  std::vector<uint8_t> key(2 * sizeof(int32_t) + 8 * sizeof(int64_t));
+  if (graphable) {
+    const int32_t flags[2] = {sp->mask, sp->mask_idx};      // baked into the captured launches (the scatter and its argument)
+    memcpy(key.data(), flags, sizeof(flags));
+    // job_items picks kernels (sel_gemm_rows, splitk_ws): a graph captured under another job size must not be replayed
+    const int64_t dims[8] = {(int64_t)(uintptr_t)d_tok, (int64_t)(uintptr_t)d_idx_, B, T, P, (int64_t)(uintptr_t)stream,
+                             (int64_t)(g_alloc_epoch * 2 + (esm_pad_in_batch ? 1 : 0)), job_items};
+    memcpy(key.data() + sizeof(flags), dims, sizeof(dims));
+  }
+  const bool reuse = graphable && graph_exec && key == graph_key;
+  if (!graphable || (!reuse && n_iters < 3)) {
     for (int it = 0; it < n_iters; ++it)
       if ((rc = iteration(it, nullptr))) return rc;
     return PG_OK;
   }
-  if ((rc = d_iter.ensure(4, stream))) return rc;
-  if ((rc = iteration(0, nullptr))) return rc;
-  std::vector<uint8_t> key(sizeof(pg_sample_params) + 7 * sizeof(int64_t));
-  {
-    pg_sample_params k = *sp;          // every field is baked into the captured kernel arguments (incl. iter_base)
-    memcpy(key.data(), &k, sizeof(k));
-    const int64_t dims[7] = {(int64_t)(uintptr_t)d_tok, (int64_t)(uintptr_t)d_idx_, B, T, P, (int64_t)(uintptr_t)stream,
-                             (int64_t)(g_alloc_epoch * 2 + (esm_pad_in_batch ? 1 : 0))};
-    memcpy(key.data() + sizeof(k), dims, sizeof(dims));
-  }
-  if (!graph_exec || key != graph_key) {
+  int first = 0;
+  if (!reuse) {
+    if ((rc = d_iter.ensure(graph_state_bytes(), stream))) return rc;
+    if ((rc = iteration(0, nullptr))) return rc;
+    first = 1;
+    {   // a buffer grown by iteration 0 moved the epoch: the key must describe the state the graph is captured in
+      const int64_t ep = (int64_t)(g_alloc_epoch * 2 + (esm_pad_in_batch ? 1 : 0));
+      memcpy(key.data() + 2 * sizeof(int32_t) + 6 * sizeof(int64_t), &ep, sizeof(ep));
+    }
     if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
     hipGraph_t graph = nullptr;
     PG_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -444,10 +453,12 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
     (void)hipGraphDestroy(graph);
     if (ce != hipSuccess) { graph_exec = nullptr; return fail(PG_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); }
     graph_key = key;
+    ++stat_graph_captures;
   }
-  // replay iterations 1 .. n_iters-1: the counter selects the idx slice, the Philox iteration word and the burn-in flag
-  if ((rc = launch_iter_counter(stream, d_iter.as<int32_t>(), true, 1))) return rc;
-  for (int it = 1; it < n_iters; ++it) PG_HIP(hipGraphLaunch(graph_exec, stream));
+  // replay: the counter selects the idx slice, the Philox iteration word and the burn-in flag; the parameters are this call's
+  if ((rc = launch_graph_state(stream, d_iter.as<int32_t>(), first, sp))) return rc;
+  for (int it = first; it < n_iters; ++it) PG_HIP(hipGraphLaunch(graph_exec, stream));
+  stat_graph_replays += n_iters - first;
   return PG_OK;
 }
 
@@ -478,7 +489,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   if (strict()) {
     if ((rc = h.ensure((size_t)Mp * 3 * d * 2, stream)) || (rc = ctx.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;   // [lo | hi | hi] rows
     if ((rc = qkv.ensure((size_t)Mp * 3 * d * 4, stream))) return rc;
-    if ((rc = ffn.ensure((size_t)Mp * 3 * f * 2, stream)) || (rc = ffn_f32.ensure((size_t)Mp * f * 4, stream))) return rc;
+    if ((rc = ffn.ensure((size_t)Mp * 3 * f * 2, stream))) return rc;
     if ((rc = scores.ensure((size_t)B * H * C * msa_row_scores_ld(C) * 4, stream))) return rc;
     float* Xs = x.as<float>();
     float* QKVf = qkv.as<float>();
@@ -526,6 +537,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       if (job_batch(B) * H * ((C + 63) / 64) < 384 && R >= 8) {
         const size_t need = (size_t)B * H * 16 * C * 576 * 4 + (size_t)B * H * (C / 16 + 9) * 18 * 1024;   // partial maps + P fragments
         if (need <= ((size_t)1 << 31) && !(rc = scores.ensure(need, stream))) part = scores.as<float>();
+        else if (order_items) return fail(PG_ERR_INVALID, "too many MSAs in one call for the row-split attention scratch: use smaller template batches");
       }
       if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0); }))) return rc;
     } else {
@@ -606,36 +618,79 @@ int Engine::msa_gibbs_device(int32_t* d_tok, int B, int R, int C, const int32_t*
   return PG_OK;
 }
 
-int Engine::msa_single_device(int32_t* d_tok, int R, int C, int mask_row, int target_row, const int32_t* d_step_idx,
+// generate_single for B templates of equal shape at once ("batch=32 templates").  Template b is token block
+// b; step s masks row mask_row of every template and samples row target_row of template b at d_step_idx[s][b][0..P_max) with
+// template b's own sampling parameters sp[b] (its own Philox key: the reference draws a fresh torch seed per call).  Every
+// order-changing kernel choice is taken as if a template were alone (order_items = 1), so template b's logits and tokens are
+// bit-identical with a B = 1 call on it -- and therefore independent of how templates are batched or sharded over GPUs.
+int Engine::msa_single_device(int32_t* d_tok, int B, int R, int C, int mask_row, int target_row, const int32_t* d_step_idx,
                               const int32_t* step_sample_flag_host, int n_steps, int P_max, const pg_sample_params* sp,
                               float* d_samp_logits_, int32_t* d_samp_tok_) {
-  int rc = check_msa_shape(cfg, 1, R, C);
+  int rc = check_msa_shape(cfg, B, R, C);
   if (rc) return rc;
   if (mask_row < 0 || mask_row >= R || target_row < 0 || target_row >= R) return fail(PG_ERR_INVALID, "row index out of range");
   if (P_max < 0 || n_steps < 0) return fail(PG_ERR_INVALID, "negative size");
-  if (n_steps == 0) return PG_OK;
+  if (n_steps == 0 || B == 0) return PG_OK;
+  if (B > 1 && (int64_t)R * C <= 2048) {
+    // few-token regime: K-splits and the weight-streaming GEMM are picked by the local shape there, so a
+    // batch would not reproduce the single calls -- run the templates one after the other (launch-bound either way)
+    for (int b = 0; b < B; ++b) {
+      // template b's steps, contiguous [n_steps][P_max]
+      if ((rc = tmp_idx.ensure((size_t)(n_steps * (size_t)P_max + 1) * 4, stream))) return rc;
+      for (int s2 = 0; s2 < n_steps && P_max > 0; ++s2)
+        PG_HIP(hipMemcpyAsync(tmp_idx.as<int32_t>() + (size_t)s2 * P_max, d_step_idx + ((size_t)s2 * B + b) * P_max, (size_t)P_max * 4,
+                              hipMemcpyDeviceToDevice, stream));
+      // per-template outputs land in scratch-free strided form: sample into temporaries, then scatter
+      float* lg_b = nullptr;
+      int32_t* st_b = nullptr;
+      if (d_samp_logits_ || d_samp_tok_) {
+        if ((rc = tmp_out.ensure((size_t)n_steps * (P_max > 0 ? P_max : 1) * cfg.vocab * 4 + (size_t)n_steps * (P_max > 0 ? P_max : 1) * 4, stream))) return rc;
+        lg_b = d_samp_logits_ ? tmp_out.as<float>() : nullptr;
+        st_b = d_samp_tok_ ? (int32_t*)(tmp_out.as<float>() + (size_t)n_steps * (P_max > 0 ? P_max : 1) * cfg.vocab) : nullptr;
+      }
+      if ((rc = msa_single_device(d_tok + (size_t)b * R * C, 1, R, C, mask_row, target_row, tmp_idx.as<int32_t>(), step_sample_flag_host,
+                                  n_steps, P_max, sp + b, lg_b, st_b))) return rc;
+      for (int s2 = 0; s2 < n_steps && P_max > 0; ++s2) {
+        if (lg_b) PG_HIP(hipMemcpyAsync(d_samp_logits_ + ((size_t)s2 * B + b) * P_max * cfg.vocab, lg_b + (size_t)s2 * P_max * cfg.vocab,
+                                        (size_t)P_max * cfg.vocab * 4, hipMemcpyDeviceToDevice, stream));
+        if (st_b) PG_HIP(hipMemcpyAsync(d_samp_tok_ + ((size_t)s2 * B + b) * P_max, st_b + (size_t)s2 * P_max, (size_t)P_max * 4,
+                                        hipMemcpyDeviceToDevice, stream));
+      }
+    }
+    return PG_OK;
+  }
   const int V = cfg.vocab;
-  if ((rc = d_rowmap.ensure(8, stream))) return rc;
-  const int32_t maps[2] = {mask_row, target_row};
-  PG_HIP(hipMemcpyAsync(d_rowmap.p, maps, 8, hipMemcpyHostToDevice, stream));
-  PG_HIP(hipStreamSynchronize(stream));     // `maps` is a stack buffer
+  if ((rc = d_rowmap.ensure((size_t)2 * B * 4, stream))) return rc;
+  std::vector<int32_t> maps((size_t)2 * B);
+  for (int b = 0; b < B; ++b) {
+    maps[b] = b * R + mask_row;
+    maps[B + b] = b * R + target_row;
+  }
+  PG_HIP(hipMemcpyAsync(d_rowmap.p, maps.data(), maps.size() * 4, hipMemcpyHostToDevice, stream));
+  PG_HIP(hipStreamSynchronize(stream));     // `maps` is a local buffer
   const int32_t* d_mask_map = d_rowmap.as<int32_t>();
-  const int32_t* d_tgt_map = d_rowmap.as<int32_t>() + 1;
-  if (!d_samp_logits_ && (rc = logits.ensure((size_t)(P_max > 0 ? P_max : 1) * V * 4, stream))) return rc;
-  pg_sample_params p = *sp;
+  const int32_t* d_tgt_map = d_rowmap.as<int32_t>() + B;
+  const int64_t n_draws = (int64_t)B * P_max;
+  if (!d_samp_logits_ && (rc = logits.ensure((size_t)(n_draws > 0 ? n_draws : 1) * V * 4, stream))) return rc;
+  struct OrderGuard { Engine& e; int64_t prev; ~OrderGuard() { e.order_items = prev; } } guard{*this, order_items};
+  order_items = 1;
   for (int s = 0; s < n_steps; ++s) {
-    const int32_t* idx_s = d_step_idx + (size_t)s * P_max;
+    const int32_t* idx_s = d_step_idx + (size_t)s * n_draws;
     if (P_max > 0)   // generate_single always masks (esm_msa_sampler.py:133), row -1 regardless of the target row
-      if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, C, idx_s, d_mask_map, 1, P_max, sp->mask_idx); }))) return rc;
+      if ((rc = timed(PC_SAMPLE, [&] { return launch_mask_scatter(stream, d_tok, C, idx_s, d_mask_map, B, P_max, sp->mask_idx); }))) return rc;
     static const int prune = [] { const char* e = getenv("PGIBBS_PRUNE_LAST"); return e ? atoi(e) : 1; }();
     const bool pruned = prune && !strict() && P_max > 0 && (int64_t)P_max * 2 < (int64_t)R * C;
-    if ((rc = pruned ? msa_trunk(d_tok, 1, R, C, idx_s, d_tgt_map, P_max, P_max) : msa_trunk(d_tok, 1, R, C))) return rc;
+    if ((rc = pruned ? msa_trunk(d_tok, B, R, C, idx_s, d_tgt_map, P_max, n_draws) : msa_trunk(d_tok, B, R, C))) return rc;
     if (P_max == 0) continue;
-    float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)s * P_max * V : logits.as<float>();
-    if ((rc = pruned ? head(nullptr, nullptr, 1, 1, P_max, lg, x_sel.as<float>()) : head(idx_s, d_tgt_map, P_max, C, P_max, lg))) return rc;
-    int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)s * P_max : nullptr;
-    p.burnin = step_sample_flag_host[s] ? 0x7fffffff : 0;   // sample=(pass_num < burn_in), esm_msa_sampler.py:143
-    if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg, V, 1, idx_s, d_tgt_map, 1, P_max, &p, s, st); }))) return rc;
+    float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)s * n_draws * V : logits.as<float>();
+    if ((rc = pruned ? head(nullptr, nullptr, 1, 1, n_draws, lg, x_sel.as<float>()) : head(idx_s, d_tgt_map, P_max, C, n_draws, lg))) return rc;
+    int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)s * n_draws : nullptr;
+    for (int b = 0; b < B; ++b) {           // one draw launch per template: its own Philox key, Philox row id = row_id_base
+      pg_sample_params p = sp[b];
+      p.burnin = step_sample_flag_host[s] ? 0x7fffffff : 0;   // sample=(pass_num < burn_in), esm_msa_sampler.py:143
+      if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg + (size_t)b * P_max * V, V, 1, idx_s + (size_t)b * P_max,
+                                                                      d_tgt_map + b, 1, P_max, &p, s, st ? st + (size_t)b * P_max : nullptr); }))) return rc;
+    }
   }
   return PG_OK;
 }

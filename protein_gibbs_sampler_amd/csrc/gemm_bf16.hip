@@ -25,65 +25,9 @@
 //   * epilogues fused: +bias, GELU, bf16 pack, fp32 residual read-modify-write.
 #include <stdlib.h>
 
-#include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace pg {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-#define PG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define PG_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-
-// erf-GELU, branch-free: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. below bf16/fp32 noise of the
-// surrounding GEMM), one v_rcp + one v_exp instead of ocml's piecewise erff.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  float p = 1.061405429f;
-  p = p * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  const float e = 1.0f - p * t * __expf(-z * z);       // erf(|x|/sqrt2)
-  return 0.5f * x + 0.5f * fabsf(x) * e;                 // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
-}
-
-// GELU for bf16 outputs (fc1 of the bf16 path): 0.5 x (1 + erf(x/sqrt2)) = relu(x) - |x| Phi(-|x|), with
-// log2 Phi(-t) fitted by a degree-5 polynomial on t >= 0 (max abs error of the GELU 3.2e-6 -- three orders below the
-// bf16 rounding of the result -- and a small RELATIVE error in the negative tail; the leading coefficient is negative,
-// so the power underflows to 0 for large t).  5 FMA + 1 v_exp + 2 ops; the fc1 epilogue is VALU-bound, and this is
-// half the instruction count of gelu_erf (which the fp32 outputs of the strict path keep).
-__device__ __forceinline__ float gelu_bf16out(float x) {
-  const float t = fabsf(x);
-  float p = -4.074793151e-04f;
-  p = fmaf(p, t, 6.563348950e-03f);
-  p = fmaf(p, t, -5.032995553e-02f);
-  p = fmaf(p, t, -4.618885100e-01f);
-  p = fmaf(p, t, -1.149779793e+00f);
-  p = fmaf(p, t, -1.000206717e+00f);
-  return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
-}
-
-// The same function on two values at once: the polynomial and the final multiply-add as v_pk_fma_f32 (two fp32 per
-// instruction).  Per element 1 (abs) + 2.5 + 4 (quarter-rate v_exp_f32) + 0.5 + 1 (max) = 9 issue slots instead of 12; the
-// arithmetic per element is identical (same fma chain), so results do not change.  Packs the pair to bf16.
-typedef __attribute__((ext_vector_type(2))) float pg_f32x2;
-__device__ __forceinline__ uint32_t gelu_bf16out_pack2(float x0, float x1) {
-  const pg_f32x2 x = {x0, x1};
-  const pg_f32x2 t = {fabsf(x0), fabsf(x1)};
-  pg_f32x2 p = {-4.074793151e-04f, -4.074793151e-04f};
-  p = __builtin_elementwise_fma(p, t, (pg_f32x2){6.563348950e-03f, 6.563348950e-03f});
-  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-5.032995553e-02f, -5.032995553e-02f});
-  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-4.618885100e-01f, -4.618885100e-01f});
-  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-1.149779793e+00f, -1.149779793e+00f});
-  p = __builtin_elementwise_fma(p, t, (pg_f32x2){-1.000206717e+00f, -1.000206717e+00f});
-  const pg_f32x2 e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
-  const pg_f32x2 r = {fmaxf(x0, 0.f), fmaxf(x1, 0.f)};
-  const pg_f32x2 g = __builtin_elementwise_fma(-t, e, r);
-  (void)x;
-  return pack_bf16x2(g[0], g[1]);
-}
 
 // Stage ROWS x 64 bf16 (128 B per row) into LDS.  One wave-instruction = 8 rows = 1 KiB, written
 // lane-linearly; lane l covers row (l>>3), LDS chunk (l&7), which receives global chunk (l&7)^(row&7).
@@ -212,10 +156,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
 // tiles writes 4 MB per XCD -- its whole L2 -- which otherwise evicts the X / W k-slices the main loops share through it.
 // Measured at the four ESM-1b shapes: QKV 0.589 -> 0.580 ms, fc1 0.859 -> 0.818, out-proj 0.308 -> 0.285, fc2 0.856 -> 0.818;
 // whole iteration 96.1 -> 94.1 ms.  (Non-temporal loads/stores in LayerNorm: no effect.)
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #define PG_EPI_AUX 2                                             /* buffer ops: nt */
 #define PG_EPI_STORE(p, v) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(p))
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t row_rsrc(void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000); }
 __device__ __forceinline__ f32x4 buf_load_f32x4(rsrc_t rs, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, PG_EPI_AUX));
@@ -536,12 +478,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 // without any epilogue at 1245-1273 TFLOP/s.
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, int abl = 0) {
-  // the big-tile kernel of the default dispatch: PGIBBS_GEMM_BIG=w4 / w16: the 4-wave / 16-wave kernel of gemm_w4.hip / gemm_w16.hip, default (pp) this one
+  // the big-tile kernel of the default dispatch: PGIBBS_GEMM_BIG=w16: the 16-wave kernel of gemm_w16.hip, pp: this one
   // -1 (default): per epilogue -- the 16-wave kernel for the bf16 outputs (QKV projections: 3.5-4 % faster there; fc1: its
   // one-pass GELU epilogue is 0.03 ms shorter per launch), this one for the fp32 residual GEMMs (the 16-wave kernel loses
-  // 3-4 % on those); 0 = always this one, 4 / 16 = always that kernel
-  static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? (e[1] == '1' ? 16 : 4) : 0); }();
-  if (!abl && big == 4 && K >= 128) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
+  // 3-4 % on those); 0 = always this one, 16 = always that kernel
+  static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? 16 : 0); }();
   if (!abl && (big == 16 || (big == -1 && (epi == EPI_BF16 || epi == EPI_BF16_GELU)))) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles), block(512);
@@ -835,7 +776,6 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   const long t256 = (long)(M / 256) * (N / 256), t128 = (long)(M / 128) * (N / 128);
   if (variant >= 80 && ok256) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 80);
   if (variant >= 60 && ok256) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 40);   // pp ablations 20..
-  if (variant >= 40 && ok256) return launch_gemm_w4(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 40);
   if (variant >= 20 && ok256) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);
   if (variant == 1) {
     if (ok256) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);

@@ -1,5 +1,5 @@
-// Pieces shared by the 256 x 256 tile kernels of gemm_w4.hip (4 waves) and gemm_w16.hip (16 waves): vector types, the GELU
-// forms of gemm_bf16.hip, and the LDS-staged epilogue.
+// Pieces shared by the GEMM tile kernels (gemm_bf16.hip, gemm_w16.hip; tools/probes/gemm_w4.hip): vector types, the GELU forms
+// (one definition for all kernels) and the LDS-staged epilogue of the 256 x 256 tiles with 4 or 16 waves.
 #pragma once
 #include "kernels.h"
 
@@ -14,7 +14,11 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define PG_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PG_NT_STORE(p, v) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(p))
 
-__device__ __forceinline__ float w4_gelu_erf(float x) {           // as gelu_erf in gemm_bf16.hip (fp32 outputs)
+// ---- the GELU forms, defined ONCE for every tile kernel: a batch split into shards may pick different kernels per shard, and
+// the logits must not depend on that ----
+// erf-GELU, branch-free: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. below bf16/fp32 noise of the
+// surrounding GEMM), one v_rcp + one v_exp instead of ocml's piecewise erff.  fp32 outputs (LM-head dense).
+__device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
   const float t = __frcp_rn(1.0f + 0.3275911f * z);
   float p = 1.061405429f;
@@ -22,28 +26,20 @@ __device__ __forceinline__ float w4_gelu_erf(float x) {           // as gelu_erf
   p = p * t + 1.421413741f;
   p = p * t - 0.284496736f;
   p = p * t + 0.254829592f;
-  const float e = 1.0f - p * t * __expf(-z * z);
-  return 0.5f * x + 0.5f * fabsf(x) * e;
-}
-__device__ __forceinline__ float w4_gelu_bf16out(float x) {       // as gelu_bf16out in gemm_bf16.hip (bf16 outputs)
-  const float t = fabsf(x);
-  float p = -4.074793151e-04f;
-  p = fmaf(p, t, 6.563348950e-03f);
-  p = fmaf(p, t, -5.032995553e-02f);
-  p = fmaf(p, t, -4.618885100e-01f);
-  p = fmaf(p, t, -1.149779793e+00f);
-  p = fmaf(p, t, -1.000206717e+00f);
-  return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
+  const float e = 1.0f - p * t * __expf(-z * z);       // erf(|x|/sqrt2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;                 // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
 }
 
-// The same function on two values at once: the polynomial and the final multiply-add as v_pk_fma_f32 (two fp32 per
-// instruction).  Per element 1 (abs) + 2.5 + 4 (quarter-rate v_exp_f32) + 0.5 + 1 (max) = 9 issue slots instead of 12; the
-// arithmetic per element is identical (same fma chain), so results do not change.  Packs the pair to bf16.
+// GELU of fc1 (bf16 outputs; strict mode's fused fc1 epilogue too): 0.5 x (1 + erf(x/sqrt2)) = relu(x) - |x| Phi(-|x|), with
+// log2 Phi(-t) fitted by a degree-5 polynomial on t >= 0 (max abs error of the GELU 3.2e-6 -- three orders below the bf16
+// rounding of the result -- and a small RELATIVE error in the negative tail; the leading coefficient is negative, so the power
+// underflows to 0 for large t).  Two values at once: the polynomial and the final multiply-add as v_pk_fma_f32.  Per element
+// 1 (abs) + 2.5 + 4 (quarter-rate v_exp_f32) + 0.5 + 1 (max) = 9 issue slots; the fc1 epilogue is VALU-bound.
 typedef __attribute__((ext_vector_type(2))) float pg_f32x2;
 #ifndef PG_STRICT_GELU_POLY
 #define PG_STRICT_GELU_POLY 1
 #endif
-__device__ __forceinline__ pg_f32x2 w4_gelu_poly2(float x0, float x1) {
+__device__ __forceinline__ pg_f32x2 gelu_poly2(float x0, float x1) {
   const pg_f32x2 t = {fabsf(x0), fabsf(x1)};
   pg_f32x2 p = {-4.074793151e-04f, -4.074793151e-04f};
   p = __builtin_elementwise_fma(p, t, (pg_f32x2){6.563348950e-03f, 6.563348950e-03f});
@@ -55,8 +51,8 @@ __device__ __forceinline__ pg_f32x2 w4_gelu_poly2(float x0, float x1) {
   const pg_f32x2 r = {fmaxf(x0, 0.f), fmaxf(x1, 0.f)};
   return __builtin_elementwise_fma(-t, e, r);
 }
-__device__ __forceinline__ uint32_t w4_gelu_bf16out_pack2(float x0, float x1) {
-  const pg_f32x2 g = w4_gelu_poly2(x0, x1);
+__device__ __forceinline__ uint32_t gelu_bf16out_pack2(float x0, float x1) {
+  const pg_f32x2 g = gelu_poly2(x0, x1);
   return pack_bf16x2(g[0], g[1]);
 }
 
@@ -68,7 +64,7 @@ __device__ __forceinline__ uint32_t w4_gelu_bf16out_pack2(float x0, float x1) {
 // tile.  The tile leaves through the (then idle) LDS so that every store instruction writes whole 512-B / 1-KiB output rows.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int EPI, int NW = 4, typename ElemF>
-__device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, int lane, int m0, int n0,
+__device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int wave, int lane, int m0, int n0,
                                             const float* __restrict__ bias, void* __restrict__ out, int ldo) {
   constexpr int NE = 256 / NW;                   // elements per lane
   constexpr int RB = 256 / NW;                   // bf16 pass: tile rows owned by a wave
@@ -86,8 +82,8 @@ __device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, 
       const float4 b4 = *(const float4*)(bias + n0 + n);
       uint2 p;
       if (EPI == EPI_BF16_GELU) {
-        p.x = w4_gelu_bf16out_pack2(a[0] + b4.x, a[1] + b4.y);
-        p.y = w4_gelu_bf16out_pack2(a[2] + b4.z, a[3] + b4.w);
+        p.x = gelu_bf16out_pack2(a[0] + b4.x, a[1] + b4.y);
+        p.y = gelu_bf16out_pack2(a[2] + b4.z, a[3] + b4.w);
       } else {
         p.x = pack_bf16x2(a[0] + b4.x, a[1] + b4.y);
         p.y = pack_bf16x2(a[2] + b4.z, a[3] + b4.w);
@@ -121,10 +117,10 @@ __device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, 
         const f32x4 a = elem(e, row, n);
         const float4 b4 = *(const float4*)(bias + n0 + n);
 #if PG_STRICT_GELU_POLY
-        const pg_f32x2 ga = w4_gelu_poly2(a[0] + b4.x, a[1] + b4.y), gb = w4_gelu_poly2(a[2] + b4.z, a[3] + b4.w);
+        const pg_f32x2 ga = gelu_poly2(a[0] + b4.x, a[1] + b4.y), gb = gelu_poly2(a[2] + b4.z, a[3] + b4.w);
         const float g0 = ga[0], g1 = ga[1], g2 = gb[0], g3 = gb[1];
 #else
-        const float g0 = w4_gelu_erf(a[0] + b4.x), g1 = w4_gelu_erf(a[1] + b4.y), g2 = w4_gelu_erf(a[2] + b4.z), g3 = w4_gelu_erf(a[3] + b4.w);
+        const float g0 = gelu_erf(a[0] + b4.x), g1 = gelu_erf(a[1] + b4.y), g2 = gelu_erf(a[2] + b4.z), g3 = gelu_erf(a[3] + b4.w);
 #endif
         uint2 hi, lo;
         hi.x = pack_bf16x2(g0, g1);
@@ -163,7 +159,7 @@ __device__ __forceinline__ void w4_epilogue(ElemF&& elem, char* smem, int wave, 
       const float4 b4 = *(const float4*)(bias + n0 + n);
       const int sr = (row >> 7) * 64 + (row & 63);
       float4 v = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
-      if (EPI == EPI_F32_GELU) { v.x = w4_gelu_erf(v.x); v.y = w4_gelu_erf(v.y); v.z = w4_gelu_erf(v.z); v.w = w4_gelu_erf(v.w); }
+      if (EPI == EPI_F32_GELU) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       *(float4*)(smem + sr * 1024 + (((n >> 2) ^ (sr & 63)) << 4)) = v;
     }
   };

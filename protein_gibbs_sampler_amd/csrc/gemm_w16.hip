@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
     n_loc = wn * 64 + (e >> 2) * 16 + fq * 4;
     return acc[e >> 2][e & 3];
   };
-  w4_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
+  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
     n_loc = wn * 64 + (e >> 2) * 16 + fq * 4;
     return acc[e >> 2][e & 3];
   };
-  w4_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
+  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
 // X3 [M][3K], W3 [N][3K] in the split operand layout; K = logical depth (a multiple of 32); M, N multiples of 256.

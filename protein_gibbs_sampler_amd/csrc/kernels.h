@@ -25,11 +25,7 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws = nullptr, size_t ws_bytes = 0);
 
-// the 4-wave 256x256 tile kernel (gemm_w4.hip): M, N multiples of 256, K a multiple of 64 and >= 128
-int launch_gemm_w4(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
-                   int ldw, int ldo, int epi, int abl = 0);
-
-// the 16-wave 256x256 tile kernel (gemm_w16.hip): same contract
+// the 16-wave 256x256 tile kernel (gemm_w16.hip): M, N multiples of 256, K a multiple of 64
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                     int ldw, int ldo, int epi, int abl = 0);
 // strict mode: the three split-bf16 products of a projection in one pass (gemm_w16.hip); X3 / W3 in the split operand layout,
@@ -79,6 +75,10 @@ int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores,
 int launch_gather_rows(hipStream_t s, const void* src, void* dst, const int32_t* idx, const int32_t* row_map, int P, int width,
                        int64_t n_sel, int row_bytes, const int32_t* d_iter = nullptr);
 int launch_iter_counter(hipStream_t st, int32_t* d_iter, bool set, int value);
+// graph state block (graph_state_bytes() bytes): d_iter[0] = iteration, then the call's sampling parameters -- the kernels of a
+// captured iteration read both from the device, so ONE graph serves every iteration of every call of the same shape
+size_t graph_state_bytes();
+int launch_graph_state(hipStream_t st, int32_t* d_iter, int iteration, const pg_sample_params* p);
 int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const float* beta, const float* embed,
                    const float* out_bias, float* logits, int64_t n, int d, int V, float eps);
 int launch_f32_to_bf16(hipStream_t s, const float* src, bf16_t* dst, int64_t n, float scale);

@@ -54,6 +54,8 @@ __device__ __forceinline__ float pg_exp(float x) {
   return __int_as_float(bits);
 }
 
+constexpr int kGraphArgsOffset = 4;      // int32 words: d_iter[0] = iteration, SampleArgs from byte 16 on
+
 struct SampleArgs {
   int32_t top_k;
   int32_t sample;       // 1: draw from all valid tokens regardless of top_k
@@ -75,8 +77,9 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
                                                               const int32_t* __restrict__ d_iter) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_sel * P) return;
-  if (d_iter) {               // graph replay: the iteration number lives on the device (one captured graph, replayed)
-    const int it = *d_iter;
+  if (d_iter) {               // graph replay: the iteration number AND the sampling parameters live on the device, so one
+    const int it = *d_iter;   // captured graph serves every iteration of every call with this shape (launch_graph_state)
+    a = *(const SampleArgs*)(d_iter + kGraphArgsOffset);
     idx += (size_t)it * n_sel * P;
     a.iter += (uint32_t)it;
     a.sample = it < a.burnin ? 1 : 0;
@@ -208,6 +211,37 @@ int launch_iter_counter(hipStream_t st, int32_t* d_iter, bool set, int value) {
   return 0;
 }
 
+static SampleArgs make_sample_args(const pg_sample_params* p, int iteration) {
+  SampleArgs a;
+  a.top_k = p->top_k;
+  a.sample = iteration < p->burnin ? 1 : 0;   // sample=(ii < burnin), esm_sampler.py:231
+  a.use_temp = (p->temperature == p->temperature) ? 1 : 0;  // NaN == None
+  a.temperature = a.use_temp ? p->temperature : 1.0f;
+  a.n_valid = p->n_valid;
+  for (int j = 0; j < 32; ++j) a.valid_idx[j] = j < p->n_valid ? p->valid_idx[j] : 0;
+  a.seed_lo = (uint32_t)(p->rng_seed & 0xffffffffu);
+  a.seed_hi = (uint32_t)(p->rng_seed >> 32);
+  a.stream = p->rng_stream;
+  a.row_id_base = p->row_id_base;
+  a.iter = (uint32_t)(p->iter_base + iteration);
+  a.burnin = p->burnin;
+  return a;
+}
+
+// graph state block: iteration counter + the call's sampling parameters (passed by value: no host buffer has to outlive the call)
+__global__ void graph_state_kernel(int32_t* d_iter, int value, SampleArgs a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *d_iter = value;
+    *(SampleArgs*)(d_iter + kGraphArgsOffset) = a;
+  }
+}
+size_t graph_state_bytes() { return kGraphArgsOffset * 4 + sizeof(SampleArgs); }
+int launch_graph_state(hipStream_t st, int32_t* d_iter, int iteration, const pg_sample_params* p) {
+  hipLaunchKernelGGL(graph_state_kernel, dim3(1), dim3(64), 0, st, d_iter, iteration, make_sample_args(p, 0));
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
                         int64_t n_sel, int P, int mask_idx, const int32_t* d_iter) {
   const int64_t n = n_sel * P;
@@ -226,19 +260,7 @@ int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const fl
     if (p->valid_idx[j] < 0 || p->valid_idx[j] >= V) return fail(1, "sample: valid_idx out of range");
   const int64_t n = n_sel * P;
   if (n == 0) return 0;
-  SampleArgs a;
-  a.top_k = p->top_k;
-  a.sample = iteration < p->burnin ? 1 : 0;   // sample=(ii < burnin), esm_sampler.py:231
-  a.use_temp = (p->temperature == p->temperature) ? 1 : 0;  // NaN == None
-  a.temperature = a.use_temp ? p->temperature : 1.0f;
-  a.n_valid = p->n_valid;
-  for (int j = 0; j < 32; ++j) a.valid_idx[j] = j < p->n_valid ? p->valid_idx[j] : 0;
-  a.seed_lo = (uint32_t)(p->rng_seed & 0xffffffffu);
-  a.seed_hi = (uint32_t)(p->rng_seed >> 32);
-  a.stream = p->rng_stream;
-  a.row_id_base = p->row_id_base;
-  a.iter = (uint32_t)(p->iter_base + iteration);
-  a.burnin = p->burnin;
+  const SampleArgs a = make_sample_args(p, iteration);
   hipLaunchKernelGGL(sample_writeback_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, width, logits, V,
                      compact, idx, row_map, n_sel, P, a, sampled_tokens, d_iter);
   PG_HIP(hipGetLastError());

@@ -144,20 +144,39 @@ class NativeMaskedLM:
 
     def gibbs_single_run(self, tokens, mask_row, target_row, step_idx, step_sample, params, want_logits=False,
                          want_tokens=False):
+        """generate_single on one MSA: tokens int32 [1,R,C] (in place), step_idx [n_steps, P]."""
+        assert tokens.ndim == 3 and tokens.shape[0] == 1
+        idx = np.ascontiguousarray(step_idx, dtype=np.int32)
+        lg, st = self.gibbs_single_batch_run(tokens, mask_row, target_row, idx[:, None, :], step_sample, [params], want_logits,
+                                             want_tokens)
+        return (lg[:, 0] if lg is not None else None), (st[:, 0] if st is not None else None)
+
+    def gibbs_single_batch_run(self, tokens, mask_row, target_row, step_idx, step_sample, params_list, want_logits=False,
+                               want_tokens=False):
+        """generate_single on B MSAs of equal shape in one pass (C ABI pg_msa_gibbs_single_batch_run): tokens int32 [B,R,C]
+        (in place), step_idx int32 [n_steps, B, P] (template b's own partitions, -1 padded), step_sample [n_steps],
+        params_list: one SampleParams per template."""
         tok = tokens
-        assert tok.dtype == np.int32 and tok.flags.c_contiguous and tok.ndim == 3 and tok.shape[0] == 1
-        _, R, C = tok.shape
+        assert tok.dtype == np.int32 and tok.flags.c_contiguous and tok.ndim == 3
+        B, R, C = tok.shape
         idx = np.ascontiguousarray(step_idx, dtype=np.int32)
         flags = np.ascontiguousarray(step_sample, dtype=np.int32)
-        n_steps, P = idx.shape
+        n_steps, Bi, P = idx.shape
+        assert Bi == B and len(params_list) == B and flags.shape == (n_steps,)
+        arr = (_lib.SampleParams * B)(*params_list)
         V = self.cfg["vocab"]
-        lg = np.empty((n_steps, P, V), dtype=np.float32) if want_logits else None
-        st = np.empty((n_steps, P), dtype=np.int32) if want_tokens else None
-        _lib.check(_lib.lib().pg_msa_gibbs_single_run(self.handle, _lib.ptr(tok), R, C, mask_row, target_row, _lib.ptr(idx),
-                                                     _lib.ptr(flags), n_steps, P, ctypes.byref(params),
-                                                     _lib.ptr(lg) if want_logits else None,
-                                                     _lib.ptr(st) if want_tokens else None))
+        lg = np.empty((n_steps, B, P, V), dtype=np.float32) if want_logits else None
+        st = np.empty((n_steps, B, P), dtype=np.int32) if want_tokens else None
+        _lib.check(_lib.lib().pg_msa_gibbs_single_batch_run(self.handle, _lib.ptr(tok), B, R, C, mask_row, target_row, _lib.ptr(idx),
+                                                           _lib.ptr(flags), n_steps, P, arr,
+                                                           _lib.ptr(lg) if want_logits else None,
+                                                           _lib.ptr(st) if want_tokens else None))
         return lg, st
+
+    def get_stat(self, name):
+        v = ctypes.c_int64(0)
+        _lib.check(_lib.lib().pg_engine_get_stat(self.handle, name.encode(), ctypes.byref(v)))
+        return v.value
 
     # ---- measurement -------------------------------------------------------------------------
     def prof_enable(self, on=True):

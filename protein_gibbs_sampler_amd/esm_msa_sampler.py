@@ -52,7 +52,7 @@ class ESM_MSA_sampler():
         self.rng_stream = 0
         self.record = False
         self.last_run = []
-        self.shard_over_ranks = True     # several torch.distributed ranks: generate() splits the MSAs of a batch over them
+        self.shard_over_ranks = False    # opt-in (or PGIBBS_SHARD_OVER_RANKS=1): generate() / generate_single_batch() split ONE job's MSAs over the torch.distributed ranks
 
     def untokenize_batch(self, batch):
         if hasattr(batch, "tolist"):
@@ -80,44 +80,113 @@ class ESM_MSA_sampler():
 
     # ---- single-row resampling (reference :101-147) -------------------------------------------
     def generate_single(self, seed_msa, steps=10, passes=3, burn_in=1, target_index=0, k=1, exclude_positions=None):
-        if exclude_positions is None:
-            exclude_positions = []
-        exclude_positions = set(i + 1 for i in exclude_positions)   # shift for the <cls> column
-        self._require_gpu("generate_single")
-        sequence_length = len(seed_msa[0])
-        positions = [x for x in range(1, sequence_length + 1) if x not in exclude_positions]
-        batch = self.get_init_msa(seed_msa, len(seed_msa[0]), 1)
-        R = batch.shape[1]
-        if not -R <= target_index < R:
-            raise IndexError("index %d is out of bounds for dimension 0 with size %d" % (target_index, R))
+        return self.generate_single_batch([seed_msa], steps=steps, passes=passes, burn_in=burn_in, target_index=target_index, k=k,
+                                          exclude_positions=[exclude_positions], _shard=False)[0]
 
-        # the step lists of every pass, decided up front (selection never depends on the logits)
+    def generate_single_batch(self, seed_msas, steps=10, passes=3, burn_in=1, target_index=0, k=1, exclude_positions=None,
+                              max_batch=4, _shard=None):
+        """== [self.generate_single(m, steps, passes, burn_in, target_index, k, ex) for m, ex in zip(seed_msas, exclude_positions)]
+        -- the loop of pgen_msa_revised over templates and sequences per template (reference pgen_msa_revised.py:107-115) --
+        with MSAs of equal shape resampled together, up to `max_batch` per native call (BASELINE config 5: batches of templates),
+        and, when sharding over torch.distributed ranks is switched on, contiguous blocks of the list on different GPUs.
+
+        Same interpreter-RNG consumption as the serial calls (one random.shuffle per MSA and pass, MSA-major), one torch seed per
+        MSA in list order, and the same strings: each MSA's arithmetic is independent of its batch mates (pgibbs.h
+        pg_msa_gibbs_single_batch_run).  exclude_positions: None or one list (or None) per MSA."""
+        n = len(seed_msas)
+        if exclude_positions is None:
+            exclude_positions = [None] * n
+        if len(exclude_positions) != n:
+            raise ValueError("exclude_positions: expected one list (or None) per MSA")
+        self._require_gpu("generate_single")
         from . import pyrandom
-        steps_all, flags = [], []
-        for pass_num in range(passes):
-            pyrandom.global_shuffle(positions)
-            for step in partition(positions, steps):
-                steps_all.append(list(step))
-                flags.append(1 if pass_num < burn_in else 0)
-        n_steps = len(steps_all)
-        P = max((len(s) for s in steps_all), default=0)
-        table = np.full((n_steps, 1, P), -1, dtype=np.int32)
-        for i, s in enumerate(steps_all):
-            table[i, 0, :len(s)] = s
-        tr = target_index % R
-        params = _lib.make_sample_params(True, self.model.alphabet.mask_idx, k, 0, None, self.valid_aa_idx,
-                                         self._draw_seed(), rng_stream=self.rng_stream, row_id_base=tr)
-        if isinstance(self.model.model, NativeMaskedLM):
-            tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)
-            lg, st = self.model.model.gibbs_single_run(tok, R - 1, tr, table[:, 0, :], flags, params,
-                                                       want_logits=self.record, want_tokens=self.record)
-            batch = torch.from_numpy(tok.astype(np.int64))
+        native = isinstance(self.model.model, NativeMaskedLM)
+        shard = sharding.sharding_requested(self.shard_over_ranks) if _shard is None else _shard
+        ctx = sharding.dist_context() if (native and shard) else None
+        if ctx is not None:
             if self.record:
-                self.last_run = [dict(table=table, sampled_logits=lg, sampled_tokens=st, tokens=tok.copy())]
+                raise ValueError("record=True is not supported together with shard_over_ranks (per-draw logits stay on their rank)")
+            sharding.check_same_job(ctx, sharding.job_digest(seed_msas, steps, passes, burn_in, target_index, k, exclude_positions,
+                                                             self.rng_stream), "ESM_MSA_sampler.generate_single_batch")
+            sharding.sync_host_rng(ctx)
+
+        # every MSA's step lists, decided up front in the serial order (selection never depends on the logits)
+        jobs = []
+        for seed_msa, excl in zip(seed_msas, exclude_positions):
+            excl = set(i + 1 for i in (excl or []))                    # shift for the <cls> column
+            sequence_length = len(seed_msa[0])
+            positions = [x for x in range(1, sequence_length + 1) if x not in excl]
+            batch = self.get_init_msa(seed_msa, len(seed_msa[0]), 1)
+            R = batch.shape[1]
+            if not -R <= target_index < R:
+                raise IndexError("index %d is out of bounds for dimension 0 with size %d" % (target_index, R))
+            steps_all, flags = [], []
+            for pass_num in range(passes):
+                pyrandom.global_shuffle(positions)
+                for step in partition(positions, steps):
+                    steps_all.append(list(step))
+                    flags.append(1 if pass_num < burn_in else 0)
+            jobs.append(dict(batch=batch, steps=steps_all, flags=flags, tr=target_index % R, seed=self._draw_seed()))
+        if ctx is not None:
+            seeds = sharding.broadcast_object(ctx, [j["seed"] for j in jobs])      # rank 0's torch draws
+            for j, sd in zip(jobs, seeds):
+                j["seed"] = sd
+        self.last_run = [None] * n
+        mask_idx = self.model.alphabet.mask_idx
+
+        def table_of(job, P):
+            t = np.full((len(job["steps"]), P), -1, dtype=np.int32)
+            for i, st in enumerate(job["steps"]):
+                t[i, :len(st)] = st
+            return t
+
+        lo, hi = (0, n) if ctx is None else sharding.shard_range(n, ctx.world, ctx.rank)
+        if native:
+            # equal-shape MSAs of this rank's block go through the engine together
+            groups = {}
+            for j in range(lo, hi):
+                job = jobs[j]
+                key = (tuple(job["batch"].shape), len(job["steps"]), tuple(job["flags"]), job["tr"])
+                groups.setdefault(key, []).append(j)
+            for key, members in groups.items():
+                for c0 in range(0, len(members), max(1, max_batch)):
+                    chunk = members[c0:c0 + max(1, max_batch)]
+                    P = max((len(st) for j in chunk for st in jobs[j]["steps"]), default=0)
+                    table = np.stack([table_of(jobs[j], P) for j in chunk], axis=1)         # [n_steps, b, P]
+                    tok = np.ascontiguousarray(np.concatenate([jobs[j]["batch"].numpy() for j in chunk]), dtype=np.int32)
+                    R = tok.shape[1]
+                    params = [_lib.make_sample_params(True, mask_idx, k, 0, None, self.valid_aa_idx, jobs[j]["seed"],
+                                                      rng_stream=self.rng_stream, row_id_base=jobs[j]["tr"]) for j in chunk]
+                    lg, st = self.model.model.gibbs_single_batch_run(tok, R - 1, key[3], table, list(key[2]), params,
+                                                                     want_logits=self.record, want_tokens=self.record)
+                    for i, j in enumerate(chunk):
+                        jobs[j]["batch"] = torch.from_numpy(tok[i:i + 1].astype(np.int64))
+                        if self.record:
+                            self.last_run[j] = dict(table=table[:, i:i + 1], sampled_logits=lg[:, i], sampled_tokens=st[:, i],
+                                                    tokens=tok[i:i + 1].copy())
         else:
-            batch = _gibbs.run_plugin_loop(self.model.model, batch, table, params, self.device, row_map=[tr],
-                                           mask_row_map=[R - 1], sample_flags=flags)
-        return self.untokenize_batch(batch)[target_index]
+            for job in jobs:
+                R = job["batch"].shape[1]
+                P = max((len(st) for st in job["steps"]), default=0)
+                params = _lib.make_sample_params(True, mask_idx, k, 0, None, self.valid_aa_idx, job["seed"],
+                                                 rng_stream=self.rng_stream, row_id_base=job["tr"])
+                job["batch"] = _gibbs.run_plugin_loop(self.model.model, job["batch"], table_of(job, P)[:, None, :], params, self.device,
+                                                      row_map=[job["tr"]], mask_row_map=[R - 1], sample_flags=job["flags"])
+        if ctx is not None:
+            # the one collective: the resampled rows, padded to the widest alignment, blocks in rank order
+            width = max(j["batch"].shape[2] for j in jobs)
+            mine = np.full((hi - lo, width), -1, dtype=np.int32)
+            for i, j in enumerate(range(lo, hi)):
+                row = jobs[j]["batch"][0, jobs[j]["tr"]].numpy()
+                mine[i, :len(row)] = row
+            counts = [sharding.shard_range(n, ctx.world, r)[1] - sharding.shard_range(n, ctx.world, r)[0] for r in range(ctx.world)]
+            t = torch.from_numpy(mine)
+            on_gpu = ctx.dist.get_backend() != "gloo"
+            full = sharding.gather_tokens(ctx.dist, t.to(self.device) if on_gpu else t, counts).cpu().numpy()
+            return ["".join(self.model.alphabet.get_tok(int(v)) for v in full[j, 1:jobs[j]["batch"].shape[2]]) for j in range(n)]
+        if not self.record:
+            self.last_run = []
+        return [self.untokenize_batch(job["batch"])[target_index] for job in jobs]
 
     # ---- whole-MSA resampling (reference :151-253) ------------------------------------------------
     def generate(self, n_samples, seed_msa, batch_size=1, in_order=False, max_len=None, leader_length=0,
@@ -136,8 +205,13 @@ class ESM_MSA_sampler():
         draw_seed = self._draw_seed()
         native = isinstance(self.model.model, NativeMaskedLM)
         self.last_run = []
-        ctx = sharding.dist_context() if (native and self.shard_over_ranks) else None
+        ctx = sharding.dist_context() if (native and sharding.sharding_requested(self.shard_over_ranks)) else None
         if ctx is not None:
+            if self.record:
+                raise ValueError("record=True is not supported together with shard_over_ranks (per-draw logits stay on their rank)")
+            sharding.check_same_job(ctx, sharding.job_digest(
+                n_samples, seed_msa, batch_size, in_order, max_len, leader_length, top_k, temperature, num_iters, burnin, mask,
+                num_positions, None if indexes is None else list(indexes), rollover_from_start, self.rng_stream), "ESM_MSA_sampler.generate")
             sharding.sync_host_rng(ctx)
             draw_seed = sharding.broadcast_object(ctx, draw_seed)
 
@@ -163,8 +237,6 @@ class ESM_MSA_sampler():
                 tok = sharding.run_sharded(ctx, np.ascontiguousarray(batch.numpy(), dtype=np.int32), table,
                                            generation_round * batch_size * num_sequences, num_sequences, run_block, self.device)
                 batch = torch.from_numpy(tok.astype(np.int64))
-                if self.record:
-                    self.last_run.append(dict(table=table, tokens=tok.copy()))
             elif native:
                 tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)
                 lg, st = self.model.model.gibbs_run(tok, table, params, want_logits=self.record, want_tokens=self.record)

@@ -89,7 +89,7 @@ class ESM_sampler():
         self.record = False
         self.last_run = []
         # when torch.distributed is initialised with several ranks, generate() shards each batch over them
-        self.shard_over_ranks = True
+        self.shard_over_ranks = False    # opt-in (or PGIBBS_SHARD_OVER_RANKS=1): generate() splits every batch of ONE job over the torch.distributed ranks
 
     # ---- helpers with the reference's names ----------------------------------------------------
     def untokenize_batch(self, batch, bos, eos):
@@ -178,8 +178,13 @@ class ESM_sampler():
         native = isinstance(self.model.model, NativeMaskedLM)
         self.last_run = []
         # several torch.distributed ranks (one per GPU): every batch is split contiguously over them
-        ctx = sharding.dist_context() if (native and self.shard_over_ranks) else None
+        ctx = sharding.dist_context() if (native and sharding.sharding_requested(self.shard_over_ranks)) else None
         if ctx is not None:
+            if self.record:
+                raise ValueError("record=True is not supported together with shard_over_ranks (per-draw logits stay on their rank)")
+            sharding.check_same_job(ctx, sharding.job_digest(
+                n_samples, seed_seq, batch_size, in_order, max_len, leader_length, top_k, temperature, num_iters, burnin, mask,
+                num_positions, None if indexes is None else list(indexes), rollover_from_start, self.rng_stream), "ESM_sampler.generate")
             sharding.sync_host_rng(ctx)
             draw_seed = sharding.broadcast_object(ctx, draw_seed)
 
@@ -205,8 +210,6 @@ class ESM_sampler():
                 tok = sharding.run_sharded(ctx, np.ascontiguousarray(batch.numpy(), dtype=np.int32), table,
                                            batch_n * batch_size, 1, run_block, self.device)
                 batch = torch.from_numpy(tok.astype(np.int64))
-                if self.record:
-                    self.last_run.append(dict(table=table, tokens=tok.copy()))
             elif native:
                 tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)
                 lg, st = self.model.model.gibbs_run(tok, table, params, want_logits=self.record, want_tokens=self.record)

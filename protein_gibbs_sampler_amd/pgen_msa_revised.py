@@ -45,8 +45,17 @@ def build_template_alignment(template_name, template_seq, reference_seqs, refere
     return alignment, apply_gap_threshold(alignment, gap_percent_threshold), 0
 
 
+def _is_rank0():
+    try:
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    except ImportError:
+        return True
+
+
 def pgen_msa(templates_path, references_path, output_path, seqs_per_template, keep_identical, steps, passes, burn_in, device,
-             model, alignment_size, ep, op, top_k, legacy=False, gap_percent_threshold=80, debug=False, sampler=None):
+             model, alignment_size, ep, op, top_k, legacy=False, gap_percent_threshold=80, debug=False, sampler=None,
+             template_batch=4):
     templates = list(zip(*parse_fasta(templates_path, clean="unalign", return_names=True)))
     references = parse_fasta(references_path, clean="unalign")
     if sampler is None:
@@ -58,15 +67,26 @@ def pgen_msa(templates_path, references_path, output_path, seqs_per_template, ke
         reference_db_path = tmp.name
     try:
         reference_seqs = dict(zip(*parse_fasta(reference_db_path, return_names=True)))
-        with open(output_path, "w") as outfile:
-            for template_name, template_seq in templates:
-                alignment, exclude_positions, row = build_template_alignment(
-                    template_name, template_seq, reference_seqs, reference_db_path, alignment_size, keep_identical, ep, op,
-                    legacy, gap_percent_threshold, debug)
-                for i in range(seqs_per_template):
-                    new_seq = sampler.generate_single(alignment, steps=steps, passes=passes, burn_in=burn_in, k=top_k,
-                                                      target_index=row, exclude_positions=exclude_positions)
-                    print(f">{i}_{template_name}\n{new_seq.replace('-', '')}", file=outfile, flush=True)
+        # The reference calls generate_single once per template and requested sequence, in this order
+        # (/root/reference/src/pgen/pgen_msa_revised.py:107-115).  Building the alignments consumes no interpreter RNG, so all of
+        # them are built first and the whole list of (template, i) jobs goes to generate_single_batch: same RNG consumption and
+        # strings as the serial loop, equal-shape alignments share forwards (`template_batch` per call), and with
+        # sampler.shard_over_ranks the list is split over the torch.distributed ranks (rank 0 writes the file).
+        names, msas, excludes, row = [], [], [], 0
+        for template_name, template_seq in templates:
+            alignment, exclude_positions, row = build_template_alignment(
+                template_name, template_seq, reference_seqs, reference_db_path, alignment_size, keep_identical, ep, op,
+                legacy, gap_percent_threshold, debug)
+            for i in range(seqs_per_template):
+                names.append(f"{i}_{template_name}")
+                msas.append(alignment)
+                excludes.append(exclude_positions)
+        new_seqs = sampler.generate_single_batch(msas, steps=steps, passes=passes, burn_in=burn_in, k=top_k, target_index=row,
+                                                 exclude_positions=excludes, max_batch=template_batch) if msas else []
+        if _is_rank0():
+            with open(output_path, "w") as outfile:
+                for name, new_seq in zip(names, new_seqs):
+                    print(f">{name}\n{new_seq.replace('-', '')}", file=outfile, flush=True)
     finally:
         os.unlink(reference_db_path)
 
@@ -92,6 +112,10 @@ def build_parser():
     parser.add_argument("--model", type=str, default="esm_msa1", choices=sorted(model_map), help="which model to use")
     parser.add_argument("--alignment_size", type=int, default=32, help="how many sequences (template plus references) should be in the alignments used for sequence generation.")
     parser.add_argument("--debug", action="store_true", default=False, help="run phmmer in --max mode (no pre-filters; finds very short hits).")
+    parser.add_argument("--template_batch", type=int, default=4, help="resample up to this many equal-shape alignments per forward pass (does not change the output).")
+    parser.add_argument("--shard_templates", action="store_true", default=False,
+                        help="under torchrun (one process per GPU): split the list of templates over the ranks (contiguous blocks, "
+                             "one RCCL gather of the resampled rows at the end); the output is identical to a single-GPU run.")
     add_engine_args(parser)
     return parser
 
@@ -99,10 +123,18 @@ def build_parser():
 def main(argv=None):
     args = build_parser().parse_args(argv)
     seed_everything(args.seed)
+    if args.shard_templates and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        args.device = "cuda:%d" % local
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))       # "nccl" is RCCL on ROCm
     sampler = ESM_MSA_sampler(model_map[args.model](checkpoint=args.checkpoint, precision=args.precision, synthetic=args.synthetic_weights), device=args.device)
+    sampler.shard_over_ranks = args.shard_templates
     pgen_msa(args.templates, args.references, args.o, args.seqs_per_template, args.keep_identical, args.steps, args.passes,
              args.burn_in, args.device, args.model, args.alignment_size, args.ep, args.op, args.top_k, legacy=args.legacy,
-             gap_percent_threshold=args.gap_percent_threshold, debug=args.debug, sampler=sampler)
+             gap_percent_threshold=args.gap_percent_threshold, debug=args.debug, sampler=sampler, template_batch=args.template_batch)
 
 
 if __name__ == "__main__":

@@ -38,6 +38,34 @@ def broadcast_object(ctx, obj):
     return box[0]
 
 
+def sharding_requested(flag):
+    """Batch sharding over torch.distributed ranks is OPT-IN: `sampler.shard_over_ranks = True` or PGIBBS_SHARD_OVER_RANKS=1.
+    The natural way to data-parallelise the reference API under torchrun is every rank sampling its OWN seeds; a sampler that
+    silently split each rank's batch and gathered rows across ranks would mix different jobs."""
+    import os
+    return bool(flag) or os.environ.get("PGIBBS_SHARD_OVER_RANKS", "0") not in ("", "0")
+
+
+def job_digest(*parts):
+    """Stable digest of the arguments that define a sharded job (every rank must have been called with the same ones)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in parts:
+        h.update(repr(p).encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def check_same_job(ctx, digest, what):
+    """Raise on EVERY rank (no hang in the later collective) unless all ranks passed the same job to `what`."""
+    got = [None] * ctx.world
+    ctx.dist.all_gather_object(got, digest)
+    if len(set(got)) != 1:
+        raise ValueError("%s with shard_over_ranks: the ranks were called with different arguments (seed sequences, batch_size, "
+                         "indexes, num_iters, ...); sharding splits ONE job over the ranks -- to run independent jobs per rank "
+                         "leave shard_over_ranks off (digests per rank: %s)" % (what, [g[:8] for g in got]))
+
+
 def sync_host_rng(ctx):
     """Every rank continues from rank 0's interpreter RNG state, so all ranks derive the same position tables (each rank
     generates the whole table natively and slices its block: no per-iteration communication)."""

@@ -1,3 +1,5 @@
+// PROBE, not part of libpgibbs.so (moved out of csrc/ in round 3: 5-10 % slower than the 8- / 16-wave kernels on every shape,
+// DESIGN.md section 4 item 1).  To try it again: copy next to csrc/gemm_w16.hip, add it to the Makefile and declare launch_gemm_w4.
 // 256x256 bf16 MFMA GEMM tile for gfx950 with FOUR waves per workgroup (one per SIMD), each owning a 128 x 128 block of
 // the tile in 256 accumulator registers:   out[M][N] (+)= X[M][K] . W[N][K]^T + bias[N]   (fp32 accumulate)
 //
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const bf16_t* __re
     n_loc = wn * 128 + (e >> 3) * 16 + fq * 4;
     return acc[e >> 3][e & 7];
   };
-  w4_epilogue<EPI, 4>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
+  tile256_epilogue<EPI, 4>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4m32_kernel(const bf16_t* _
     const f32x16 a = acc[bi][bj];
     return (f32x4){a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
   };
-  w4_epilogue<EPI, 4>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
+  tile256_epilogue<EPI, 4>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
 template <int ABL, int DMA0 = 16>
