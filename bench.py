@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 TOTAL_CHAINS = 256                 # BASELINE.json configs[1] / configs[2]
+SYNTH_KW = dict(std=0.025, embed_std=0.3, ln_jitter=0.1)     # seeded synthetic weights at a realistic logit scale (std ~ 10)
 
 
 def parse_args(argv=None):
@@ -65,6 +66,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-mode leg (N = 1)")
+    ap.add_argument("--no-msa", action="store_true", help="skip the ESM-MSA-1b legs (BASELINE configs 4 and 5; N = 1)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: still create the torch.distributed process group (world_size 1) and run the final all-gather "
+                         "through it, so that the RCCL path is executed on a single GPU")
     return ap.parse_args(argv)
 
 
@@ -205,9 +210,16 @@ def main():
         dev = torch.device("cuda", local_rank % n_dev)
         torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -236,7 +248,9 @@ def main():
 
     sd = lm = L_ = None
     if not dry:
-        sd = weights.synthetic_state_dict(cfg, seed=0)
+        # realistic-scale synthetic weights (logit std ~ 10, max |logit| ~ 40 -- what the full-size parity tests use): the
+        # logit-error figures this line reports are then the honest ones (N(0, 0.02) weights give logit std 0.7 and errors 15x smaller)
+        sd = weights.synthetic_state_dict(cfg, seed=0, **SYNTH_KW)
         wrapper = models.ESM1b(state_dict=sd, config=cfg, precision=args.precision)
         lm = wrapper.model.to(str(dev))
         L_ = _lib.lib()
@@ -307,7 +321,7 @@ def main():
            "data": "synthetic",
            "config": {"workload": "ESM_sampler ESM-1b (33 layers, d=1280) Gibbs: %d chains in total, %s per GPU x L=%d (T=%d), P=%d "
                                   "positions per chain per iteration, mask=True top_k=%d temperature=1.0 burnin=%s; %s; "
-                                  "synthetic N(0,0.02) weights"
+                                  "synthetic weights N(0,0.025), embeddings N(0,0.3), LayerNorm jitter 0.1 (logit std ~10)"
                                   % (B_total, "/".join(str(c) for c in sorted(set(counts))), L, T, P, top_k,
                                      "inf" if burnin == float("inf") else int(burnin),
                                      "bf16 MFMA operands, fp32 accumulate + fp32 residual stream" if args.precision == "bf16"
@@ -316,7 +330,13 @@ def main():
                       "parallelism": "chains sharded %d-way (contiguous blocks), 1 %s all-gather at the end"
                                      % (world, "RCCL" if backend == "nccl" else "gloo"),
                       "n_layers": cfg["n_layers"]},
-           "ranks_seen": dist.get_world_size() if dist is not None else 1, "backend": backend if dist is not None else None}
+           "ranks_seen": 1, "backend": backend if dist is not None else None}
+    if dist is not None:
+        # counted, not assumed: every rank contributes a one to an all-reduce on the job's backend
+        ones = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        out["ranks_seen"] = int(ones.item())
+        assert out["ranks_seen"] == world, "all_reduce saw %d ranks, WORLD_SIZE is %d" % (out["ranks_seen"], world)
     if dry:
         out["dry_run"] = True
         out["value"] = 0.0
@@ -401,11 +421,19 @@ def main():
                   show_progress_bar=False)
         random.seed(0)
         s1.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", **kw)
+        s1.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", **kw)
+        c0, r0 = lm.get_stat("graph_captures"), lm.get_stat("graph_replays")
+        n_calls = 20
         t0 = time.perf_counter()
-        for _ in range(5):
-            s1.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", **kw)
-        tg = (time.perf_counter() - t0) / 5
-        gpu_cfg1 = {"gpu_positions_per_s": 40 / tg, "gpu_ms_per_iter": 1e3 * tg / 20}
+        for _ in range(n_calls):
+            s1.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", **kw)      # one generate() per sequence, as pgen_esm.py issues them
+        tg = (time.perf_counter() - t0) / n_calls
+        gpu_cfg1 = {"gpu_positions_per_s": 40 / tg, "gpu_ms_per_iter": 1e3 * tg / 20, "gpu_ms_per_generate_call": 1e3 * tg,
+                    "generate_calls_timed": n_calls,
+                    "graph_captures_during_timing": lm.get_stat("graph_captures") - c0,
+                    "graph_replayed_iterations_during_timing": lm.get_stat("graph_replays") - r0,
+                    "note": "whole generate() calls (tokenise, position table, H2D, 20 iterations as replays of one captured "
+                            "hipGraph, D2H, untokenise); a fresh torch draw seed per call"}
         _lib.check(L_.pg_engine_set_stream(lm.handle, ctypes.c_void_p(stream.cuda_stream)))
     if rank == 0 and world == 1 and not dry and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, lm if args.precision == "bf16" else None,
@@ -416,6 +444,21 @@ def main():
             out["strict_mode"]["max_abs_logit_err"] = chk.get("fp32_max_abs_logit_err")
             out["strict_mode"]["logit_std"] = chk["logit_std"]
         out["bf16_max_abs_logit_err"] = chk.get("bf16_max_abs_logit_err")
+    # ---- N = 1: the ESM-MSA-1b configurations (BASELINE configs 4 and 5) on the same GPU, driver-timed -------------------
+    if rank == 0 and world == 1 and not dry and not args.no_msa and args.precision == "bf16":
+        import bench_msa
+        del lm_strict
+        mw, mlm, mcfg = bench_msa.build("bf16", str(dev), realistic=True)
+        _lib.check(L_.pg_engine_set_stream(mlm.handle, ctypes.c_void_p(stream.cuda_stream)))
+        c4 = bench_msa.run_config4(mw, mlm, mcfg, steps=3, warmup=1, dev=dev)
+        c5 = bench_msa.run_config5(mw, mlm, mcfg, templates=4, dev=dev, max_batch=4)
+        c5_1 = bench_msa.run_config5(mw, mlm, mcfg, templates=1, dev=dev, max_batch=1)
+        keep4 = ("value", "unit", "ms_per_step", "steps", "model_tflops", "frac_of_bf16_mfma_peak", "time_split_ms_per_iter", "config")
+        keep5 = ("value", "unit", "templates", "templates_per_call", "ms_per_forward", "ms_per_template_forward", "model_tflops",
+                 "frac_of_bf16_mfma_peak", "time_split_ms_per_forward", "config")
+        out["msa"] = {"config4": {k_: c4[k_] for k_ in keep4}, "config5": {k_: c5[k_] for k_ in keep5},
+                      "config5_one_template_per_call": {k_: c5_1[k_] for k_ in keep5},
+                      "weights": "synthetic ESM-MSA-1b (12 layers, d=768), same scale as above"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -108,12 +108,13 @@ def local_slice(table, lo, hi):
     return np.ascontiguousarray(table[:, lo:hi])
 
 
-def gather_tokens(dist, local_tokens, counts=None):
+def gather_tokens(dist, local_tokens, counts=None, force_padded=False):
     """The one collective: all-gather of the final token buffers (equal shards -> all_gather_into_tensor,
-    ragged -> all_gather of padded blocks).  `dist` is torch.distributed; works on RCCL ("nccl") and gloo."""
+    ragged -> all_gather of padded blocks; force_padded takes the ragged form for equal shards too -- how the single-GPU
+    RCCL test executes it).  `dist` is torch.distributed; works on RCCL ("nccl") and gloo."""
     import torch
     world = dist.get_world_size()
-    if counts is None or len(set(counts)) == 1:
+    if counts is None or (len(set(counts)) == 1 and not force_padded):
         out = torch.empty((world * local_tokens.shape[0],) + tuple(local_tokens.shape[1:]), dtype=local_tokens.dtype,
                           device=local_tokens.device)
         if dist.get_backend() == "gloo":
@@ -122,7 +123,7 @@ def gather_tokens(dist, local_tokens, counts=None):
         else:
             dist.all_gather_into_tensor(out, local_tokens.contiguous())
         return out
-    mx = max(counts)
+    mx = max(counts) + (1 if force_padded else 0)
     pad = torch.zeros((mx,) + tuple(local_tokens.shape[1:]), dtype=local_tokens.dtype, device=local_tokens.device)
     pad[:local_tokens.shape[0]] = local_tokens
     parts = [torch.empty_like(pad) for _ in range(world)]

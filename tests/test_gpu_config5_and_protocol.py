@@ -115,6 +115,39 @@ def test_config5_first_step_logits_equal_unpruned_forward(msa_model):
     assert d < 2e-2          # same arithmetic up to the GEMM kernel chosen for 51 rows vs 65 664 rows (bf16 rounding flips)
 
 
+def test_config5_four_templates_per_call_equal_four_serial_calls(msa_model):
+    """Row e5 (BASELINE config 5: 32 templates over 8 GPUs = 4 per GPU): four templates of depth 128 x L = 512 resampled in ONE
+    native call per step -- 4 x 65 664 tokens per forward -- give, bit for bit, the logits, tokens and strings of four
+    generate_single calls (the reference's loop, pgen_msa_revised.py:107-115), with the same interpreter-RNG consumption and one
+    torch seed per template."""
+    R, L, steps, passes, burn_in = 128, 512, 10, 3, 2
+    s = esm_msa_sampler.ESM_MSA_sampler(msa_model, device="cuda:0")
+    s.record = True
+    msas = [_template_msa(R, L, seed=100 + i) for i in range(4)]
+    excl = [None, [0, 7, 300], None, list(range(500, 512))]
+    random.seed(21)
+    torch.manual_seed(4)
+    serial, runs = [], []
+    for m, e in zip(msas, excl):
+        serial.append(s.generate_single(list(m), steps=steps, passes=passes, burn_in=burn_in, target_index=0, k=1, exclude_positions=e))
+        runs.append(s.last_run[0])
+    state = random.getrandbits(32)
+    random.seed(21)
+    torch.manual_seed(4)
+    batched = s.generate_single_batch([list(m) for m in msas], steps=steps, passes=passes, burn_in=burn_in, target_index=0, k=1,
+                                      exclude_positions=excl, max_batch=4)
+    assert random.getrandbits(32) == state
+    assert batched == serial
+    for one, many in zip(runs, s.last_run):
+        P = one["table"].shape[-1]
+        assert (many["table"][:, :, :P] == one["table"]).all()
+        valid = one["table"][:, 0] >= 0
+        assert np.array_equal(many["sampled_logits"][:, :P][valid], one["sampled_logits"][valid])       # bit for bit
+        assert (many["sampled_tokens"][:, :P][valid] == one["sampled_tokens"][valid]).all()
+        assert (many["tokens"] == one["tokens"]).all()
+    assert len(set(serial)) == 4
+
+
 # ---- the reference's plug-in protocol ------------------------------------------------------------------------------
 def test_native_model_call_protocol_esm():
     """`self.model.model(batch)["logits"]` exactly as /root/reference/src/pgen/esm_sampler.py:223 issues it: an int64 torch

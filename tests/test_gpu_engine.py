@@ -141,6 +141,46 @@ def test_graph_replay_matches_eager_loop():
     assert again == outs[0]
 
 
+def test_graph_is_captured_once_and_replayed_by_later_calls():
+    """BASELINE config 1's shape of use -- one generate() per sequence, a fresh draw seed, top_k and burn-in per call: the
+    few-token loop captures ONE iteration once and every later call of the same shape replays it for ALL its iterations (the
+    sampling parameters live in a device-side state block).  Asserts the path taken (pg_engine_get_stat) and that the replayed
+    calls equal the eager loop (record=True) draw for draw."""
+    ck = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=80)
+    sd = synthetic_esm_weights(EsmConfig(**ck), seed=31, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    s = esm_sampler.ESM_sampler(_model(ck, sd), device="cuda:0")
+    lm = s.model.model
+    seed = "MEPAATGQEAEECAHSGRGEAWEEV"
+    kw = dict(batch_size=1, num_iters=20, mask=True, num_positions_percent=10, show_progress_bar=False)
+    variants = [dict(top_k=1, burnin=10), dict(top_k=3, burnin=5, temperature=0.7), dict(top_k=0), dict(top_k=1, burnin=0)]
+
+    def run(record):
+        outs = []
+        for i, v in enumerate(variants * 2):
+            s.draw_seed, s.record = 100 + i, record
+            random.seed(i)
+            outs.append(s.generate(1, seed, **kw, **v))
+        return outs
+
+    c0, r0 = lm.get_stat("graph_captures"), lm.get_stat("graph_replays")
+    replayed = run(False)
+    caps, reps = lm.get_stat("graph_captures") - c0, lm.get_stat("graph_replays") - r0
+    assert caps == 1, caps                                  # one capture for eight calls with different parameters
+    assert reps == 8 * 20 - 1, reps                         # every iteration but the very first (eager, sizes the buffers)
+    # two-iteration calls reuse the graph too (no capture is started for fewer than three iterations, but an existing one serves)
+    s.draw_seed, s.record = 7, False
+    random.seed(3)
+    a = s.generate(1, seed, **dict(kw, num_iters=2), top_k=1, burnin=1)
+    assert lm.get_stat("graph_replays") - r0 == reps + 2 and lm.get_stat("graph_captures") - c0 == 1
+    eager = run(True)                                       # recording takes the eager loop
+    assert lm.get_stat("graph_replays") - r0 == reps + 2
+    assert replayed == eager
+    assert len({o[0] for o in replayed}) > 2
+    s.draw_seed, s.record = 7, True
+    random.seed(3)
+    assert s.generate(1, seed, **dict(kw, num_iters=2), top_k=1, burnin=1) == a
+
+
 @pytest.mark.parametrize("precision,tol", [("bf16", BF16_TOL), ("fp32", STRICT_TOL)])
 def test_padded_ragged_batch_forward(precision, tol):
     """A right-padded ragged batch, as the reference's log_likelihood_batch hands to `model.model(batch)`

@@ -178,3 +178,33 @@ def test_msa_generate_single_native(target_index):
         tok[0, tr, st] = want
     assert (tok == run["tokens"]).all()
     assert out == s.untokenize_batch(tok)[target_index]
+
+
+def test_generate_single_batch_equals_serial_calls_small_msas():
+    """Row e5 on small alignments (the few-token regime: the engine runs the batch's templates one after the other) and on a
+    list with mixed shapes and exclusion lists: strings, recorded logits and tokens equal the serial generate_single calls."""
+    ocfg = MsaConfig(**CK)
+    sd = synthetic_msa_weights(ocfg, seed=8, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    s = esm_msa_sampler.ESM_MSA_sampler(_model(sd), device="cuda:0")
+    s.record = True
+    a = ["ACDEFGHIKLMNPQ", "ACDEFGHIKLMNPQ", "AC-EFGHIKLMNPV"]
+    b = ["MEPAATGQEAEECA", "MEP-ATGQEAEECA", "MKPAATGQ--EECA"]
+    c = ["ACDEFGHIKL", "ACDEFGHIKV"]
+    msas, excl = [a, b, c, a, b], [[0, 5], None, [], [1], [2, 3, 4]]
+    random.seed(2)
+    torch.manual_seed(9)
+    serial, runs = [], []
+    for m, e in zip(msas, excl):
+        serial.append(s.generate_single(m, steps=4, passes=2, burn_in=1, target_index=-1, k=2, exclude_positions=e))
+        runs.append(s.last_run[0])
+    state = random.getrandbits(32)
+    random.seed(2)
+    torch.manual_seed(9)
+    batched = s.generate_single_batch(msas, steps=4, passes=2, burn_in=1, target_index=-1, k=2, exclude_positions=excl, max_batch=3)
+    assert batched == serial and random.getrandbits(32) == state
+    for j, (one, many) in enumerate(zip(runs, s.last_run)):
+        P = one["table"].shape[-1]
+        assert (many["table"][:, :, :P] == one["table"]).all() and (many["table"][:, :, P:] == -1).all()
+        valid = one["table"][:, 0] >= 0
+        assert np.array_equal(many["sampled_logits"][:, :P][valid], one["sampled_logits"][valid]), j
+        assert (many["sampled_tokens"][:, :P][valid] == one["sampled_tokens"][valid]).all() and (many["tokens"] == one["tokens"]).all()
