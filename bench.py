@@ -416,6 +416,8 @@ def main():
         # BASELINE config 1 on the GPU: one chain, L = 25 (T = 27), P = 2, 20 iterations, top_k = 1, burnin = 10
         import random
         from protein_gibbs_sampler_amd import esm_sampler
+        lm.set_job_items(0)            # config 1 is a whole job of its own, not a shard of the 256-chain job (r02's 4.27 ms/iteration
+                                       # was this: the single chain ran with the big job's kernel choices)
         s1 = esm_sampler.ESM_sampler(wrapper, device=str(dev))
         kw = dict(batch_size=1, num_iters=20, burnin=10, mask=True, in_order=False, num_positions_percent=10, top_k=1,
                   show_progress_bar=False)

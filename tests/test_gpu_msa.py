@@ -5,6 +5,7 @@ import random
 import warnings
 
 import numpy as np
+import torch
 import pytest
 
 from oracle import draw as odraw
