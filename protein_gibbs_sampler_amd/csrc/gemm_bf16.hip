@@ -171,7 +171,8 @@ __device__ __forceinline__ void buf_store_f32x4(f32x4 v, rsrc_t rs, int voff, in
 
 template <int EPI, bool NO_STORE = false>
 __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int wm, int wn, int wave, int lane, int m0,
-                                             int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo) {
+                                             int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo,
+                                             const EpiAux& aux) {
   const int fr = lane & 15, fq = lane >> 4;
   __syncthreads();
   // fp32-staged epilogues (fp32 outputs, and fc1's bf16+GELU).  Two phases; in phase p EVERY wave stages its accumulator
@@ -179,7 +180,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
   // staged rows w*16.. = token rows m0 + (w>>2)*128 + (4p + (w&3))*16 + it and moves them out as whole 1-KiB rows.
   // Residual variant: the 16 row loads of a phase (64 VGPRs) are issued BEFORE that phase's LDS staging, and phase 1's
   // loads before phase 0's stores, so a tile exposes about one memory latency instead of four.
-  if (EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_F32_RESID) {
+  if (EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN) {
     auto stage = [&](int p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -223,7 +224,21 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       }
       return;
     }
-    if (EPI == EPI_F32_RESID) {
+    if (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN) {
+      // EPI_F32_RESID_LN (LayerNorm folded into the neighbouring GEMMs, gemm_epilogue.h): a lane's four values are columns
+      // 4*lane .. of the row, so the 16 lanes of a DPP row hold one 64-column segment -- its partial sums and the bf16 copy
+      // of the updated row leave from here too.
+      // c_row of this wave's 32 rows: lane l < 16 holds the one of phase 0's row l, lanes 16-31 phase 1's
+      float cv = 0.f;
+      if (EPI == EPI_F32_RESID_LN) cv = aux.center_in[(lane < 16 ? grow(0) : grow(1) - 16) + (lane & 31)];
+      auto ln_out = [&](const f32x4 xn, int row, float c) {
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const uint2 pk = ln_operand_pack(xn, c);
+        u32x2_t* dst = (u32x2_t*)(aux.xb + (size_t)row * ldo + n0 + lane * 4);
+        if (aux.flags & 1) __builtin_nontemporal_store((u32x2_t){pk.x, pk.y}, dst);
+        else *dst = (u32x2_t){pk.x, pk.y};
+        ln_partial_store(xn, aux.stats_out + ((size_t)row * kLnStatPitch + (n0 >> 6) + (lane >> 4)) * 2, lane);
+      };
       // Row-shaped accesses as buffer ops: wave-uniform row base in the resource, the row step in an SGPR offset, one
       // VGPR (lane*16) for all 64 accesses -- 64-bit per-row VGPR addresses would not leave room for 32 rows in flight.
       const rsrc_t rs0 = row_rsrc((float*)out + (size_t)grow(0) * ldo + n0);
@@ -243,7 +258,9 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep);
+        const f32x4 xn = r0[it] + v;
+        buf_store_f32x4(xn, rs0, voff, it * rstep);
+        if (EPI == EPI_F32_RESID_LN) ln_out(xn, grow(0) + it, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), it)));
       }
       __syncthreads();
       stage(1);
@@ -252,7 +269,9 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep);
+        const f32x4 xn = r1[it] + v;
+        buf_store_f32x4(xn, rs1, voff, it * rstep);
+        if (EPI == EPI_F32_RESID_LN) ln_out(xn, grow(1) + it, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), 16 + it)));
       }
       return;
     }
@@ -321,16 +340,23 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
 template <int EPI, int ABL = 0, int GM = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+                                                          int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
+                                                          int tail_m0, EpiAux aux) {
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
+  // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
+  if (ABL == 0 && (int)blockIdx.x < n_tail) {
+    const int tn64 = tiles_n * 4, bt = blockIdx.x;
+    gemm_tail_tile64<8, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, nullptr, aux);
+    return;
+  }
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2;                      // 0: leads, 1: lags by one barrier
   const int wm = grp, wn = wave & 3;              // wave tile: rows wm*128.. of X, rows wn*64.. of W
 
-  int bid = blockIdx.x;
+  int bid = blockIdx.x - n_tail;
   if (ABL == 18 && (bid & 7) != 0) return;        // timing experiment: only the workgroups of XCD 0 run (1/8 of the tiles)
   if (ABL == 19 && (bid & 7) > 1) return;         // ... XCDs 0 and 1
   {
@@ -452,7 +478,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
+  epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo, aux);
 }
 
 // Measured alternatives that were NOT faster on MI355X and were removed again (QKV GEMM, M=66048 N=3840 K=1280, steady-state
@@ -476,38 +502,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 // the bytes (bf16 0.09, fp32 0.16, fp32 read-modify-write 0.32 ms at this shape = 5.5-6.3 TB/s), a lone workgroup's
 // epilogue takes < 2 us against 6 us per tile when all 256 CUs store together.  The vendor BLAS runs the same four shapes
 // without any epilogue at 1245-1273 TFLOP/s.
+// M rows of 256 x 256 tiles (M may be 0) + tail_rows rows of 64 x 64 tail tiles starting at row M, one grid
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi, int abl = 0) {
-  // the big-tile kernel of the default dispatch: PGIBBS_GEMM_BIG=w16: the 16-wave kernel of gemm_w16.hip, pp: this one
-  // -1 (default): per epilogue -- the 16-wave kernel for the bf16 outputs (QKV projections: 3.5-4 % faster there; fc1: its
-  // one-pass GELU epilogue is 0.03 ms shorter per launch), this one for the fp32 residual GEMMs (the 16-wave kernel loses
-  // 3-4 % on those); 0 = always this one, 16 = always that kernel
-  static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? 16 : 0); }();
-  if (!abl && (big == 16 || (big == -1 && (epi == EPI_BF16 || epi == EPI_BF16_GELU)))) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, 0);
+                     int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0, const EpiAux* aux = nullptr) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
-  dim3 grid(n_tiles), block(512);
+  const int n_tail = (tail_rows / 64) * (N / 64), tail_m0 = M;
+  const EpiAux ax = aux ? *aux : EpiAux{};
+  dim3 grid(n_tiles + n_tail), block(512);
+#define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax
   if (abl) {   // ablations: EPI_BF16 only
-    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 13) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 14) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 13>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 18) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 18>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 19) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 19>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 28) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 18>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 29) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 17) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 17>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 16) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 15) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 15>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
-    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
+    if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 3) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 3>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 13) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 13>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 14) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 13>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 18) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 18>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 19) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 19>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 28) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 18>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 29) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 0>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 17) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 17>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 16) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 16>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 15) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 15>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 12) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 12>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 10) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 10>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 11) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 11>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 8) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 8>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 9) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 9>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 4) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 1>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 5) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 8>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 6) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 2>), grid, block, 0, s, PG_PP_ARGS);
+    if (abl == 7) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 0, 16>), grid, block, 0, s, PG_PP_ARGS);
     PG_HIP(hipGetLastError());
     return 0;
   }
@@ -517,22 +541,51 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   const int gm = gm_env ? gm_env : (K >= 4096 ? 2 : 4);
 #define PG_GEMM_CASE(E)                                                                                                   \
   case E:                                                                                                                 \
-    if (gm == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 1>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
-    else if (gm == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 2>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
-    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
+    if (gm == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 1>), grid, block, 0, s, PG_PP_ARGS); \
+    else if (gm == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 2>), grid, block, 0, s, PG_PP_ARGS); \
+    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<E>), grid, block, 0, s, PG_PP_ARGS); \
     break;
   switch (epi) {
     PG_GEMM_CASE(EPI_BF16)
     PG_GEMM_CASE(EPI_BF16_GELU)
     PG_GEMM_CASE(EPI_F32_RESID)
+    PG_GEMM_CASE(EPI_F32_RESID_LN)
     PG_GEMM_CASE(EPI_F32)
     PG_GEMM_CASE(EPI_F32_GELU)
     default:
-      return fail(1, "gemm: bad epilogue");
+      return fail(1, "gemm: bad epilogue for the 8-wave tile kernel");
   }
 #undef PG_GEMM_CASE
+#undef PG_PP_ARGS
   PG_HIP(hipGetLastError());
   return 0;
+}
+
+// The big-batch GEMM: whole rounds of 256 x 256 tiles (one per CU) plus, in the SAME grid, 64 x 64 tail tiles for the rows
+// beyond the last full round when that round would be mostly empty (gemm_epilogue.h).  Kernel per epilogue: the 16-wave kernel
+// for the bf16 outputs (QKV projections: 3.5-4 % faster there; fc1: its one-pass GELU epilogue is 0.03 ms shorter per launch),
+// the 8-wave ping-pong kernel for the fp32 outputs (the 16-wave kernel loses 3-4 % on the residual read-modify-write);
+// PGIBBS_GEMM_BIG=pp / w16 forces one kernel for the plain epilogues.  M, N multiples of 256, K a multiple of 64, K >= 128.
+int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
+                    int ldw, int ldo, int epi, const EpiAux* aux) {
+  if (M % 256 || N % 256 || K % 64 || K < 128 || M < 256) return fail(1, "gemm_big: shape");
+  static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+  static const int tail_on = [] { const char* e = getenv("PGIBBS_GEMM_TAIL"); return e ? atoi(e) : 1; }();
+  static const int tail_max = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_MAX"); return e ? atoi(e) : 4; }();   // tail tiles per CU at most
+  static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? 16 : 0); }();
+  const int tiles_n = N / 256, tiles_m = M / 256;
+  const long t256 = (long)tiles_m * tiles_n, full = t256 / n_cu, frac = t256 - full * n_cu;
+  int m_main = tiles_m, tail_rows = 0;
+  if (tail_on && frac > 0) {
+    const int mm = (int)(full * n_cu / tiles_n);             // m-panels that fill whole rounds (0: less than one round of big tiles)
+    const long n_tail = (long)(tiles_m - mm) * 4 * (N / 64);
+    if (n_tail <= (long)tail_max * n_cu) { m_main = mm; tail_rows = (tiles_m - mm) * 256; }
+  }
+  const bool lnf = epi == EPI_BF16_LNF || epi == EPI_BF16_GELU_LNF;
+  const bool bf16out = epi == EPI_BF16 || epi == EPI_BF16_GELU || lnf;
+  const bool use16 = lnf || (epi != EPI_F32_RESID_LN && (big == 16 || (big == -1 && bf16out)));
+  if (use16) return launch_gemm_w16(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows, aux);
+  return launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows, aux);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,31 +834,7 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
     if (ok256) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
     if (ok128) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   }
-  if (ok256 && t256 >= 128) {
-    // The 256^2 kernel runs (nearly) whole rounds of one tile per CU: time / ceil(tiles / 256) is the same 20 x 1.55 us per
-    // K = 1280 tile for all four shapes, so 1290 tiles cost 6 rounds, not 5.04.  When the last round would be less than
-    // half full, the m-panels beyond the full rounds are peeled off into a second, small GEMM, which the dispatch below
-    // gives to the 64^2 / 128^2 / split-K kernels (512 rows at config 2).  Measured: out-proj 0.283 -> 0.269 ms, fc2
-    // 0.800 -> 0.785, QKV and fc1 unchanged; whole iteration 92.7 -> 91.1 ms.  (An earlier attempt that peeled into the
-    // 128^2 kernel alone gained nothing.)
-    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-    static const int peel_on = [] { const char* e = getenv("PGIBBS_GEMM_PEEL"); return e ? atoi(e) : 1; }();
-    const int tiles_n = N / 256, tiles_m = M / 256;
-    const long full = t256 / n_cu, frac = t256 - full * n_cu;
-    const int m_main = (int)(full * n_cu / tiles_n);
-    const int peel_rows = (tiles_m - m_main) * 256;
-    if (peel_on && frac > 0 && 2 * frac <= n_cu && full >= 1 && m_main > 0 && peel_rows <= 4096) {
-      int rc = launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi);
-      if (rc) return rc;
-      const size_t esz = (epi == EPI_BF16 || epi == EPI_BF16_GELU) ? 2 : 4;
-      // no split-K scratch for the peeled rows: every row of a large batch then goes through the same sequence of fp32
-      // accumulations whichever kernel computes it, so results do not depend on where a chain sits in the batch or on
-      // how the chains are sharded over GPUs (split-K would save 17 us per fc2 launch)
-      return launch_gemm_bf16_variant(s, X + (size_t)m_main * 256 * ldx, W, bias, (char*)out + (size_t)m_main * 256 * ldo * esz,
-                                      peel_rows, N, K, ldx, ldw, ldo, epi, variant, nullptr, 0);
-    }
-    return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
-  }
+  if (ok256 && t256 >= 128) return launch_gemm_big(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, nullptr);
   if (ok128 && (t128 >= 200 || !(M % 64 == 0))) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }

@@ -59,18 +59,246 @@ __device__ __forceinline__ uint32_t gelu_bf16out_pack2(float x0, float x1) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMMs around it (bf16 mode, big batches; engine.hip `fold_ln`).
+//   producer (out-proj / fc2, EPI_F32_RESID_LN): x += acc + bias as before, and additionally (a) a bf16 copy of the updated
+//     residual row -- the NEXT GEMM's operand -- and (b) per row and per 64-column segment the partial sums (sum x, sum x^2);
+//   consumer (QKV / fc1, EPI_BF16_LNF / EPI_BF16_GELU_LNF): W' = bf16(W . gamma) is multiplied with the RAW bf16 row and the
+//     normalisation is applied to the accumulator:  LN(x) . W^T + b = rstd (x . W'^T - mean . s) + b',
+//     s_n = sum_k W'[n][k], b'_n = b_n + sum_k W[n][k] beta_k (host, at upload).
+// This removes the LayerNorm kernel (one fp32 read + one bf16 write of the whole residual stream per LayerNorm) for one extra
+// bf16 row store in the producer's epilogue.  Every piece below is shared by the 256 x 256 tiles and the 64 x 64 tail tiles, so
+// a row gets bit-identical statistics, operand row and output whichever tile shape computes it (shard invariance).
+// ---------------------------------------------------------------------------------------------------------------------
+// Centring: the operand copy is bf16(x - c_row) with c_row = the row's mean at the PREVIOUS LayerNorm (LayerNorm is invariant
+// under a per-row shift, so the consumer only replaces mean by mean - c_row): the bf16 rounding then acts on a row whose mean is
+// ~0, as it does on the LayerNorm kernel's output, instead of on |x| -- without it the folded form loses accuracy when a row's
+// mean is not small against its spread.  Consumers publish their rows' means (tile column 0 only) for the next producer;
+// two arrays alternate so that nobody reads what a neighbour tile of the same launch writes.
+constexpr int kLnStatPitch = 32;     // partial-sum slots per row (64-column segments: d_model <= 2048); unused slots stay zero
+struct EpiAux {
+  bf16_t* xb;              // producer: bf16 copy of the updated, centred rows, [M][ldo]
+  float* stats_out;        // producer: partial sums [M][kLnStatPitch][2]
+  const float* stats_in;   // consumer: the operand rows' partial sums [M][kLnStatPitch][2]
+  const float* colsum;     // consumer: s_n [N]
+  const float* center_in;  // both: c_row [M] the operand copy was / is to be centred with
+  float* center_out;       // consumer: the rows' means, for the next producer
+  float inv_n, eps;        // consumer: 1 / d_model, LayerNorm epsilon
+  int flags;               // experiments (PGIBBS_FOLD_FLAGS): 1 = non-temporal operand-copy stores, 2 = timing only: no statistics loads
+};
+
+#define PG_DPP_ADD(v, ctrl) \
+  __fadd_rn((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true)))
+// all-reduce over the 16 lanes of a DPP row (= one 64-column segment, 4 columns per lane), fixed tree:
+// lane ^ 1 (quad_perm [1,0,3,2]), lane ^ 2 (quad_perm [2,3,0,1]), the other quad of the half (row_half_mirror), the other half
+// (row_mirror); fp32 addition is commutative, so all 16 lanes end with the same bits
+__device__ __forceinline__ float seg16_sum(float v) {
+  v = PG_DPP_ADD(v, 0xB1);
+  v = PG_DPP_ADD(v, 0x4E);
+  v = PG_DPP_ADD(v, 0x141);
+  v = PG_DPP_ADD(v, 0x140);
+  return v;
+}
+// x = 4 consecutive columns of the updated residual row held by this lane; seg_stats = &stats[(row * kLnStatPitch + segment) * 2]
+__device__ __forceinline__ void ln_partial_store(const f32x4 x, float* seg_stats, int lane) {
+  float s1 = __fadd_rn(__fadd_rn(x[0], x[1]), __fadd_rn(x[2], x[3]));
+  float s2 = __fadd_rn(__fmaf_rn(x[0], x[0], __fmul_rn(x[1], x[1])), __fmaf_rn(x[2], x[2], __fmul_rn(x[3], x[3])));
+  s1 = seg16_sum(s1);
+  s2 = seg16_sum(s2);
+  if ((lane & 15) == 0) *(float2*)seg_stats = make_float2(s1, s2);
+}
+// (mean, rstd) of a row from its partial sums: all kLnStatPitch slots (the unused ones hold zeros), sixteen independent 16-B
+// loads issued together -- a loop over the used slots would serialise as many memory round trips in the tile's prologue --
+// summed in slot order
+__device__ __forceinline__ float2 ln_row_stats(const float* part, float inv_n, float eps) {
+  float4 q[kLnStatPitch / 2];
+#pragma unroll
+  for (int i = 0; i < kLnStatPitch / 2; ++i) q[i] = ((const float4*)part)[i];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnStatPitch / 2; ++i) {
+    s1 = __fadd_rn(__fadd_rn(s1, q[i].x), q[i].z);
+    s2 = __fadd_rn(__fadd_rn(s2, q[i].y), q[i].w);
+  }
+  const float mean = __fmul_rn(s1, inv_n);
+  const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(s2, inv_n)), 0.f);
+  return make_float2(mean, __frsqrt_rn(__fadd_rn(var, eps)));
+}
+// consumer prologue for one operand row: its (mean - c_row, rstd); the tile column 0 also publishes the mean
+__device__ __forceinline__ float2 ln_consumer_row(const EpiAux& aux, int row, bool publish) {
+  if (aux.flags & 2) return make_float2(0.f, 1.f);
+  const float2 st = ln_row_stats(aux.stats_in + (size_t)row * kLnStatPitch * 2, aux.inv_n, aux.eps);
+  const float c = aux.center_in[row];
+  if (publish) aux.center_out[row] = st.x;
+  return make_float2(__fsub_rn(st.x, c), st.y);
+}
+// producer: the centred bf16 operand copy of 4 consecutive columns
+__device__ __forceinline__ uint2 ln_operand_pack(const f32x4 xn, float c) {
+  uint2 pk;
+  pk.x = pack_bf16x2(__fsub_rn(xn[0], c), __fsub_rn(xn[1], c));
+  pk.y = pack_bf16x2(__fsub_rn(xn[2], c), __fsub_rn(xn[3], c));
+  return pk;
+}
+__device__ __forceinline__ float ln_fold_apply(float acc, float2 st, float colsum, float bias) {
+  return __fmaf_rn(st.y, __fmaf_rn(-st.x, colsum, acc), bias);
+}
+template <int EPI> struct EpiTraits {
+  static constexpr bool lnf = EPI == EPI_BF16_LNF || EPI == EPI_BF16_GELU_LNF;
+  static constexpr bool bf16out = EPI == EPI_BF16 || EPI == EPI_BF16_GELU || lnf;
+  static constexpr bool gelu_bf16 = EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELU_LNF;
+  static constexpr bool resid = EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 64 x 64 "tail" tile computed by a whole 8- or 16-wave workgroup of the 256 x 256 kernels.  1290 tiles on 256 CUs are
+// 5.04 rounds: the rows beyond the last full round used to go to a second, serial launch of the 64 x 64 kernel (3.5 ms of a
+// 90 ms iteration at 100-330 TFLOP/s on an otherwise idle chip).  They are now extra workgroups at the FRONT of the same grid:
+// one 64 x 64 tile each, K walked through a ring of eight 16-KB stages (the tile kernel's 128 KB of LDS) so that seven K-steps
+// of LDS-DMA are in flight -- the tile is latency-, not throughput-bound -- and one s_barrier per K-step.  Same MFMA
+// instruction and k order as every other tile kernel: a row's result does not depend on which tile shape computed it.
+//   stage = 64 X rows + 64 W rows of 128 B = 16 pieces of 1 KiB (8 rows each); wave w stages piece w (and w + 8 with 8 waves)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NW, int EPI>
+__device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                 const float* __restrict__ bias, void* __restrict__ out, int K, int ldx, int ldw,
+                                                 int ldo, int m0, int n0, char* smem, float2* rowstat, const EpiAux& aux) {
+  static_assert(NW == 8 || NW == 16, "tail tile: 8 or 16 waves");
+  constexpr int STAGES = 8, STAGE_BYTES = 16384, PPW = 16 / NW, TM = 16 / NW;
+  typedef EpiTraits<EPI> T;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nk = K / 64;
+
+  if (T::lnf && threadIdx.x < 64)       // (mean, rstd) of the tile's 64 operand rows; published by the K loop's barriers
+    rowstat[threadIdx.x] = ln_consumer_row(aux, m0 + threadIdx.x, n0 == 0);
+
+  // piece p (0-7: X rows 8p .., 8-15: W rows 8(p-8) ..): wave w stages piece w, and with 8 waves also piece w + 8 -- so piece A is
+  // an X piece for w < 8 and piece B (8 waves only) always a W piece.  (No arrays of buffer resources: the type is opaque.)
+  const bool a_is_w = wave >= 8;
+  const int ld_a = a_is_w ? ldw : ldx;
+  const bf16_t* src_a = a_is_w ? W + (size_t)(n0 + (wave - 8) * 8) * ldw : X + (size_t)(m0 + wave * 8) * ldx;
+  const rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src_a, 0, (7 * ld_a + K) * 2, 0x00020000);
+  const int voff_a = ((lane >> 3) * ld_a + ((lane & 7) ^ (lane >> 3)) * 8) * 2;
+  const rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)(n0 + (wave & 7) * 8) * ldw), 0, (7 * ldw + K) * 2, 0x00020000);
+  const int voff_b = ((lane >> 3) * ldw + ((lane & 7) ^ (lane >> 3)) * 8) * 2;
+  auto dma = [&](int t) {
+    char* dst = smem + (t & (STAGES - 1)) * STAGE_BYTES;
+    const int soff = t < nk ? t * 128 : 0x7f000000;          // past the end of K: out of range, no memory traffic
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, PG_LDS_PTR(dst + wave * 1024), 16, voff_a, soff, 0, 0);
+    if (PPW == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, PG_LDS_PTR(dst + (wave + 8) * 1024), 16, voff_b, soff, 0, 0);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int fo0 = fr * 128 + ((fq ^ (fr & 7)) << 4);
+  const int fo1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
+  const int ni = NW == 16 ? (wave >> 2) : (wave >> 1);       // 16-row block of W (output columns)
+  const int mi0 = NW == 16 ? (wave & 3) : (wave & 1) * 2;    // first 16-row block of X (output rows)
+  f32x4 acc[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t) dma(t);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PPW) : "memory");     // my pieces of K-step t have landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();          // everybody's have; everybody is done reading the slot of step t-1
+    __builtin_amdgcn_sched_barrier(0);
+    dma(t + STAGES - 1);                   // ... which the pieces of step t+7 now overwrite
+    const char* sb = smem + (t & (STAGES - 1)) * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = kk ? fo1 : fo0;
+      const bf16x8 wf = *(const bf16x8*)(sb + 8192 + ni * 2048 + fo);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const bf16x8 xf = *(const bf16x8*)(sb + (mi0 + j) * 2048 + fo);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing zero-fill pieces, before the LDS is reused
+
+  // lane holds D[n = ni*16 + fq*4 + r][m = (mi0 + j)*16 + fr], r = 0..3
+  const int n_loc = ni * 16 + fq * 4;
+  const float4 b4 = *(const float4*)(bias + n0 + n_loc);
+  if (EPI == EPI_F32_RESID_LN) {
+    // through LDS into row shape (16 lanes x 4 columns = the 64-column segment), then exactly the row code of the big tile
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m_loc = (mi0 + j) * 16 + fr;
+      *(float4*)(smem + m_loc * 256 + n_loc * 4) = make_float4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 16 / NW; ++ps) {
+      const int row = (ps * NW + wave) * 4 + (lane >> 4), c = lane & 15;
+      const f32x4 v = *(const f32x4*)(smem + row * 256 + c * 16);
+      float* gp = (float*)out + (size_t)(m0 + row) * ldo + n0 + c * 4;
+      const f32x4 xn = *(const f32x4*)gp + v;
+      *(f32x4*)gp = xn;
+      *(uint2*)(aux.xb + (size_t)(m0 + row) * ldo + n0 + c * 4) = ln_operand_pack(xn, aux.center_in[m0 + row]);
+      ln_partial_store(xn, aux.stats_out + ((size_t)(m0 + row) * kLnStatPitch + (n0 >> 6)) * 2, lane);
+    }
+    return;
+  }
+  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (T::lnf) cs4 = *(const float4*)(aux.colsum + n0 + n_loc);
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m_loc = (mi0 + j) * 16 + fr;
+    float v0, v1, v2, v3;
+    if (T::lnf) {
+      const float2 st = rowstat[m_loc];
+      v0 = ln_fold_apply(acc[j][0], st, cs4.x, b4.x);
+      v1 = ln_fold_apply(acc[j][1], st, cs4.y, b4.y);
+      v2 = ln_fold_apply(acc[j][2], st, cs4.z, b4.z);
+      v3 = ln_fold_apply(acc[j][3], st, cs4.w, b4.w);
+    } else {
+      v0 = acc[j][0] + b4.x; v1 = acc[j][1] + b4.y; v2 = acc[j][2] + b4.z; v3 = acc[j][3] + b4.w;
+    }
+    const size_t o = (size_t)(m0 + m_loc) * ldo + n0 + n_loc;
+    if (T::bf16out) {
+      uint2 p;
+      p.x = T::gelu_bf16 ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
+      p.y = T::gelu_bf16 ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
+      *(uint2*)((bf16_t*)out + o) = p;
+    } else if (EPI == EPI_F32_RESID) {
+      float4* dst = (float4*)((float*)out + o);
+      float4 r = *dst;
+      r.x += v0; r.y += v1; r.z += v2; r.w += v3;
+      *dst = r;
+    } else {
+      if (EPI == EPI_F32_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+      *(float4*)((float*)out + o) = make_float4(v0, v1, v2, v3);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Epilogue of a 256 x 256 tile held by NW waves (4 or 16).  A lane holds 256 / NW "elements": four consecutive output features
 // (n) of one token row (m).  elem(e, m_loc, n_loc) returns element e (compile-time after unrolling) and its position inside the
 // tile.  The tile leaves through the (then idle) LDS so that every store instruction writes whole 512-B / 1-KiB output rows.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int EPI, int NW = 4, typename ElemF>
 __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int wave, int lane, int m0, int n0,
-                                            const float* __restrict__ bias, void* __restrict__ out, int ldo) {
+                                            const float* __restrict__ bias, void* __restrict__ out, int ldo,
+                                            const float2* rowstat = nullptr, const EpiAux* aux = nullptr) {
   constexpr int NE = 256 / NW;                   // elements per lane
   constexpr int RB = 256 / NW;                   // bf16 pass: tile rows owned by a wave
   constexpr int RF = 128 / NW;                   // fp32 passes: staged rows owned by a wave
   __syncthreads();                               // every wave is done with the operand ring
-  if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
+  if (EpiTraits<EPI>::bf16out) {
+    float2 st4[4];                               // folded LayerNorm: a lane's elements lie in four rows (e & 3)
+    if (EpiTraits<EPI>::lnf) {
+      static_assert(!EpiTraits<EPI>::lnf || NW == 16, "folded LayerNorm: element order of the 16-wave kernel");
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int row, n;
+        (void)elem(e, row, n);
+        st4[e] = rowstat[row];
+      }
+    }
     // one pass: the whole 256 x 256 bf16 tile (128 KB) as 256 rows of 512 B, chunk-swizzled by row.  The GELU of fc1 is
     // applied in registers on the way in: +0.053 ms on the fc1 launch against +0.085 for fp32 staging in two passes with the
     // GELU on the way out (the ping-pong kernel's form); splitting the tile in two halves so that the stores of one drain
@@ -80,13 +308,24 @@ __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int w
       int row, n;
       const f32x4 a = elem(e, row, n);
       const float4 b4 = *(const float4*)(bias + n0 + n);
-      uint2 p;
-      if (EPI == EPI_BF16_GELU) {
-        p.x = gelu_bf16out_pack2(a[0] + b4.x, a[1] + b4.y);
-        p.y = gelu_bf16out_pack2(a[2] + b4.z, a[3] + b4.w);
+      float v0, v1, v2, v3;
+      if (EpiTraits<EPI>::lnf) {       // folded LayerNorm: rstd (acc - mean s_n) + b'_n
+        const float4 cs4 = *(const float4*)(aux->colsum + n0 + n);
+        const float2 st = st4[e & 3];
+        v0 = ln_fold_apply(a[0], st, cs4.x, b4.x);
+        v1 = ln_fold_apply(a[1], st, cs4.y, b4.y);
+        v2 = ln_fold_apply(a[2], st, cs4.z, b4.z);
+        v3 = ln_fold_apply(a[3], st, cs4.w, b4.w);
       } else {
-        p.x = pack_bf16x2(a[0] + b4.x, a[1] + b4.y);
-        p.y = pack_bf16x2(a[2] + b4.z, a[3] + b4.w);
+        v0 = a[0] + b4.x; v1 = a[1] + b4.y; v2 = a[2] + b4.z; v3 = a[3] + b4.w;
+      }
+      uint2 p;
+      if (EpiTraits<EPI>::gelu_bf16) {
+        p.x = gelu_bf16out_pack2(v0, v1);
+        p.y = gelu_bf16out_pack2(v2, v3);
+      } else {
+        p.x = pack_bf16x2(v0, v1);
+        p.y = pack_bf16x2(v2, v3);
       }
       *(uint2*)(smem + row * 512 + (((n >> 3) ^ (row & 31)) << 4) + (n & 4) * 2) = p;
     }

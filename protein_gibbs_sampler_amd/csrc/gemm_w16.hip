@@ -48,14 +48,22 @@ __device__ unsigned long long* pg_w16_prof;      // [workgroup][4]: shader clock
 template <int EPI, int GM, int ABL>
 __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                                const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                               int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+                                                               int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
+                                                               int tail_m0, EpiAux aux) {
   __shared__ __attribute__((aligned(16))) char smem[2 * W16_KSLOT];
+  __shared__ float2 rowstat[EpiTraits<EPI>::lnf ? 256 : 1];      // folded LayerNorm: (mean, rstd) of the tile's operand rows
 
+  // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
+  if (ABL == 0 && (int)blockIdx.x < n_tail) {
+    const int tn64 = tiles_n * 4, bt = blockIdx.x;
+    gemm_tail_tile64<16, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, rowstat, aux);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave & 3, wn = wave >> 2;           // wave tile: X rows wm*64 .., W rows wn*64 ..
 
-  int bid = blockIdx.x;
+  int bid = blockIdx.x - n_tail;
   {
     const int xcd = bid & 7, q = n_tiles >> 3, r = n_tiles & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -104,6 +112,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   dma_step(0);
+  if (EpiTraits<EPI>::lnf && threadIdx.x < 256)      // under the first DMA's latency; published by the K loop's barriers
+    rowstat[threadIdx.x] = ln_consumer_row(aux, m0 + threadIdx.x, n0 == 0);
   PG_W16_T(0);
   for (int t = 0; t < nk; ++t) {
     if ((ABL != 1 && ABL != 10) || t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of K-step t have landed
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
     n_loc = wn * 64 + (e >> 2) * 16 + fq * 4;
     return acc[e >> 2][e & 3];
   };
-  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
+  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo, rowstat, &aux);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
     n_loc = wn * 64 + (e >> 2) * 16 + fq * 4;
     return acc[e >> 2][e & 3];
   };
-  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
+  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo, nullptr, nullptr);
 }
 
 // X3 [M][3K], W3 [N][3K] in the split operand layout; K = logical depth (a multiple of 32); M, N multiples of 256.
@@ -290,16 +300,18 @@ template <int ABL>
 static int launch_w16_abl(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int K, int ldx, int ldw,
                           int ldo, int tiles_n, int n_tiles) {
   hipLaunchKernelGGL((gemm_bf16_w16_kernel<EPI_BF16, 4, ABL>), dim3(n_tiles), dim3(1024), 0, s, X, W, bias, out, K, ldx, ldw, ldo,
-                     tiles_n, n_tiles);
+                     tiles_n, n_tiles, 0, 0, EpiAux{});
   PG_HIP(hipGetLastError());
   return 0;
 }
 
 // M, N multiples of 256; K a multiple of 64.  abl > 0: micro-benchmark variants (bf16 epilogue only)
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
-                    int ldw, int ldo, int epi, int abl) {
+                    int ldw, int ldo, int epi, int abl, int tail_rows, const EpiAux* aux) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
-  if (M % 256 || N % 256 || K % 64 || K < 64 || n_tiles < 1) return fail(1, "gemm_w16: shape");
+  const int n_tail = (tail_rows / 64) * (N / 64), tail_m0 = M;
+  const EpiAux ax = aux ? *aux : EpiAux{};
+  if (M % 256 || N % 256 || K % 64 || K < 64 || tail_rows % 64 || n_tiles + n_tail < 1) return fail(1, "gemm_w16: shape");
   switch (abl) {
     case 0: break;
     case 1: return launch_w16_abl<1>(s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
@@ -311,15 +323,17 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
   }
   static const int gm_env = [] { const char* e = getenv("PGIBBS_GEMM_GM"); return e ? atoi(e) : 0; }();
   const int gm = gm_env ? gm_env : (K >= 4096 ? 2 : 4);
-  dim3 grid(n_tiles), block(1024);
+  dim3 grid(n_tiles + n_tail), block(1024);
 #define PG_W16_CASE(E)                                                                                                     \
   case E:                                                                                                                  \
-    if (gm == 2) hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 2, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles); \
-    else hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 4, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);     \
+    if (gm == 2) hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 2, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax); \
+    else hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 4, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax);     \
     break;
   switch (epi) {
     PG_W16_CASE(EPI_BF16)
     PG_W16_CASE(EPI_BF16_GELU)
+    PG_W16_CASE(EPI_BF16_LNF)
+    PG_W16_CASE(EPI_BF16_GELU_LNF)
     PG_W16_CASE(EPI_F32_RESID)
     PG_W16_CASE(EPI_F32)
     PG_W16_CASE(EPI_F32_GELU)
