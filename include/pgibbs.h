@@ -226,17 +226,14 @@ int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t*
  * (GELU, then the split operand rows fc2 reads; N a multiple of 256; out = hi + lo of those rows) */
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi);
-/* LayerNorm folded into the two GEMMs around it, as the engine chains them at big batches (csrc/gemm_epilogue.h):
- *   x1 = resid + a @ w1^T + b1                     producer: also emits bf16(x1) and per-row partial sums per 64 columns
- *   y  = f(LN(x1; gamma, beta) @ w2^T + b2)        consumer: rstd (bf16(x1) @ (w2 gamma)^T - mean s) + b2'; f = GELU if gelu
- * a [M][K1], w1 [d][K1], b1 [d], resid [M][d] (overwritten with x1), gamma / beta [d], w2 [N2][d], b2 [N2], y [M][N2] (the bf16
- * result widened), stats_out [M][d/64][2] and means_out [M] (the row means the consumer publishes) optional; the operand copy
- * is centred with per-row values of magnitude center_scale (the engine uses the previous LayerNorm's row means).
- * M, d, N2 multiples of 256; K1 of 64; d <= 2048.  Rows beyond the last full round of
- * 256 x 256 tiles go through the 64 x 64 tail tiles, exactly as in the engine. */
-int pg_dbg_ln_fold_pair(int device, const float* a, const float* w1, const float* b1, float* resid_inout, const float* gamma,
-                        const float* beta, const float* w2, const float* b2, float* y, float* stats_out, float* means_out,
-                        float center_scale, int M, int K1, int d, int N2, int gelu, float eps);
+/* The residual GEMM that also normalises (csrc/gemm_epilogue.h, EPI_F32_RESID_LN), as the engine runs out-proj / fc2 at big
+ * batches:  x = resid + a @ w^T + bias, and the workgroup that completes a row panel writes h = LayerNorm(x; gamma, beta) of its
+ * rows.  resid_inout [M][N] is overwritten with x; h_fused = that launch's h (bf16 widened), h_kernel = the stand-alone
+ * LayerNorm kernel on the same x: the two must be bit-identical.  `repeats` launches back to back (the arrival counters reset
+ * themselves).  M, N multiples of 256, N <= 2048, K a multiple of 64.  Rows beyond the last full round of 256 x 256 tiles go
+ * through 64 x 64 tail tiles, exactly as in the engine. */
+int pg_dbg_gemm_resid_ln(int device, const float* a, const float* w, const float* bias, float* resid_inout, const float* gamma,
+                         const float* beta, float* h_fused, float* h_kernel, int M, int N, int K, float eps, int repeats);
 /* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events; M a multiple of 16,
  * of 64 above 256); variant 1 =
  * lockstep kernel, 2 = ping-pong kernel; epi: 0 bf16 out, 1 bf16+gelu, 2 fp32 residual, 3 fp32, 4 fp32+gelu */

@@ -497,68 +497,61 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
   return PG_OK;
 }
 
-int pg_dbg_ln_fold_pair(int device, const float* a, const float* w1, const float* b1, float* resid_inout, const float* gamma,
-                        const float* beta, const float* w2, const float* b2, float* y, float* stats_out, float* means_out,
-                        float center_scale, int M, int K1, int d, int N2, int gelu, float eps) {
-  if (!a || !w1 || !b1 || !resid_inout || !gamma || !beta || !w2 || !b2 || !y) return fail(PG_ERR_INVALID, "pg_dbg_ln_fold_pair: null argument");
-  if (M < 256 || M % 256 || d % 256 || N2 % 256 || K1 % 64 || K1 < 128 || d < 256 || d > 64 * kLnStatPitch) return fail(PG_ERR_INVALID, "pg_dbg_ln_fold_pair: shape");
+int pg_dbg_gemm_resid_ln(int device, const float* a, const float* w, const float* bias, float* resid_inout, const float* gamma,
+                         const float* beta, float* h_fused, float* h_kernel, int M, int N, int K, float eps, int repeats) {
+  if (!a || !w || !bias || !resid_inout || !gamma || !beta || !h_fused || !h_kernel) return fail(PG_ERR_INVALID, "pg_dbg_gemm_resid_ln: null argument");
+  if (M < 256 || M % 256 || N % 256 || K % 64 || K < 128 || N > 2048 || repeats < 1) return fail(PG_ERR_INVALID, "pg_dbg_gemm_resid_ln: shape");
   DeviceGuard g(-1);
   int rc = dbg_device(device);
   if (rc) return rc;
   Tmp t;
-  const int nseg = d / 64;
-  float* tmp = (float*)t.get((size_t)std::max((size_t)M * K1, std::max((size_t)d * K1, (size_t)N2 * d)) * 4);
-  bf16_t* ba = (bf16_t*)t.get((size_t)M * K1 * 2);
-  bf16_t* bw1 = (bf16_t*)t.get((size_t)d * K1 * 2);
-  bf16_t* bw2 = (bf16_t*)t.get((size_t)N2 * d * 2);
-  float* db1 = (float*)t.get((size_t)d * 4);
-  float* dx = (float*)t.get((size_t)M * d * 4);
-  bf16_t* xb = (bf16_t*)t.get((size_t)M * d * 2);
-  float* st = (float*)t.get((size_t)M * kLnStatPitch * 2 * 4);
-  float* cen = (float*)t.get((size_t)2 * M * 4);
-  float* db2 = (float*)t.get((size_t)N2 * 4);
-  float* dcs = (float*)t.get((size_t)N2 * 4);
-  bf16_t* by = (bf16_t*)t.get((size_t)M * N2 * 2);
-  float* dy = (float*)t.get((size_t)M * N2 * 4);
-  if (!tmp || !ba || !bw1 || !bw2 || !db1 || !dx || !xb || !st || !cen || !db2 || !dcs || !by || !dy) return fail(PG_ERR_HIP, "hipMalloc failed");
-  std::vector<float> wf((size_t)N2 * d), bp((size_t)N2), cs((size_t)N2);
-  fold_ln_into_weights(w2, b2, gamma, beta, 1.f, N2, d, wf.data(), bp.data(), cs.data());
-  PG_HIP(hipMemcpy(tmp, a, (size_t)M * K1 * 4, hipMemcpyHostToDevice));
-  if ((rc = launch_f32_to_bf16(nullptr, tmp, ba, (int64_t)M * K1, 1.f))) return rc;
+  float* tmp = (float*)t.get((size_t)std::max((size_t)M * K, (size_t)N * K) * 4);
+  bf16_t* ba = (bf16_t*)t.get((size_t)M * K * 2);
+  bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2);
+  float* db = (float*)t.get((size_t)N * 4);
+  float* dg = (float*)t.get((size_t)N * 4);
+  float* dbt = (float*)t.get((size_t)N * 4);
+  float* dx = (float*)t.get((size_t)M * N * 4);
+  float* dx0 = (float*)t.get((size_t)M * N * 4);
+  bf16_t* h1 = (bf16_t*)t.get((size_t)M * N * 2);
+  bf16_t* h2 = (bf16_t*)t.get((size_t)M * N * 2);
+  float* hf = (float*)t.get((size_t)M * N * 4);
+  int* cnt = (int*)t.get((size_t)(M / 64 + 8) * 4);           // zero-filled by Tmp::get
+  if (!tmp || !ba || !bw || !db || !dg || !dbt || !dx || !dx0 || !h1 || !h2 || !hf || !cnt) return fail(PG_ERR_HIP, "hipMalloc failed");
+  PG_HIP(hipMemcpy(tmp, a, (size_t)M * K * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, tmp, ba, (int64_t)M * K, 1.f))) return rc;
   PG_HIP(hipDeviceSynchronize());
-  PG_HIP(hipMemcpy(tmp, w1, (size_t)d * K1 * 4, hipMemcpyHostToDevice));
-  if ((rc = launch_f32_to_bf16(nullptr, tmp, bw1, (int64_t)d * K1, 1.f))) return rc;
-  PG_HIP(hipDeviceSynchronize());
-  PG_HIP(hipMemcpy(tmp, wf.data(), (size_t)N2 * d * 4, hipMemcpyHostToDevice));
-  if ((rc = launch_f32_to_bf16(nullptr, tmp, bw2, (int64_t)N2 * d, 1.f))) return rc;
-  PG_HIP(hipMemcpy(db1, b1, (size_t)d * 4, hipMemcpyHostToDevice));
-  PG_HIP(hipMemcpy(db2, bp.data(), (size_t)N2 * 4, hipMemcpyHostToDevice));
-  PG_HIP(hipMemcpy(dcs, cs.data(), (size_t)N2 * 4, hipMemcpyHostToDevice));
-  PG_HIP(hipMemcpy(dx, resid_inout, (size_t)M * d * 4, hipMemcpyHostToDevice));
-  EpiAux ap{}, ac{};
-  // centring values: something of the size of a row mean, different per row (a previous LayerNorm's means in the engine)
-  {
-    std::vector<float> c(M);
-    for (int i = 0; i < M; ++i) c[i] = center_scale * (float)((i * 37) % 101 - 50) / 50.0f;
-    PG_HIP(hipMemcpy(cen, c.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(tmp, w, (size_t)N * K * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, tmp, bw, (int64_t)N * K, 1.f))) return rc;
+  PG_HIP(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(dg, gamma, (size_t)N * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(dbt, beta, (size_t)N * 4, hipMemcpyHostToDevice));
+  PG_HIP(hipMemcpy(dx0, resid_inout, (size_t)M * N * 4, hipMemcpyHostToDevice));
+  EpiAux aux{};
+  aux.h = h1;
+  aux.gamma = dg;
+  aux.beta = dbt;
+  aux.counters = cnt;
+  aux.eps = eps;
+  // repeated launches: the arrival counters must reset themselves, and who arrives last varies from launch to launch
+  if (!gemm_big_can_fuse_ln(M, N, K)) return fail(PG_ERR_UNSUPPORTED, "pg_dbg_gemm_resid_ln: a row panel's tiles would span XCDs at this shape");
+  for (int r = 0; r < repeats; ++r) {
+    PG_HIP(hipMemcpyAsync(dx, dx0, (size_t)M * N * 4, hipMemcpyDeviceToDevice, nullptr));
+    PG_HIP(hipMemsetAsync(h1, 0xff, (size_t)M * N * 2, nullptr));
+    if ((rc = launch_gemm_big(nullptr, ba, bw, db, dx, M, N, K, K, K, N, EPI_F32_RESID_LN, &aux))) return rc;
   }
-  ap.xb = xb;
-  ap.stats_out = st;
-  ap.center_in = cen;
-  ac.stats_in = st;
-  ac.colsum = dcs;
-  ac.center_in = cen;
-  ac.center_out = cen + M;
-  ac.inv_n = 1.0f / (float)d;
-  ac.eps = eps;
-  if ((rc = launch_gemm_big(nullptr, ba, bw1, db1, dx, M, d, K1, K1, K1, d, EPI_F32_RESID_LN, &ap))) return rc;
-  if ((rc = launch_gemm_big(nullptr, xb, bw2, db2, by, M, N2, d, d, d, N2, gelu ? EPI_BF16_GELU_LNF : EPI_BF16_LNF, &ac))) return rc;
-  if ((rc = launch_bf16_to_f32(nullptr, by, dy, (int64_t)M * N2))) return rc;
+  if ((rc = launch_layernorm_bf16(nullptr, dx, dg, dbt, h2, M, N, eps))) return rc;      // the stand-alone kernel on the same rows
+  if ((rc = launch_bf16_to_f32(nullptr, h1, hf, (int64_t)M * N))) return rc;
   PG_HIP(hipDeviceSynchronize());
-  PG_HIP(hipMemcpy(resid_inout, dx, (size_t)M * d * 4, hipMemcpyDeviceToHost));
-  PG_HIP(hipMemcpy(y, dy, (size_t)M * N2 * 4, hipMemcpyDeviceToHost));
-  if (stats_out) PG_HIP(hipMemcpy2D(stats_out, (size_t)nseg * 8, st, (size_t)kLnStatPitch * 8, (size_t)nseg * 8, M, hipMemcpyDeviceToHost));
-  if (means_out) PG_HIP(hipMemcpy(means_out, cen + M, (size_t)M * 4, hipMemcpyDeviceToHost));
+  PG_HIP(hipMemcpy(h_fused, hf, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  if ((rc = launch_bf16_to_f32(nullptr, h2, hf, (int64_t)M * N))) return rc;
+  PG_HIP(hipDeviceSynchronize());
+  PG_HIP(hipMemcpy(h_kernel, hf, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  PG_HIP(hipMemcpy(resid_inout, dx, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  std::vector<int> c((size_t)M / 64 + 8);
+  PG_HIP(hipMemcpy(c.data(), cnt, c.size() * 4, hipMemcpyDeviceToHost));
+  for (int v : c)
+    if (v != 0) return fail(PG_ERR_HIP, "pg_dbg_gemm_resid_ln: an arrival counter did not return to zero");
   return PG_OK;
 }
 

@@ -33,19 +33,13 @@ enum ProfClass { PC_GEMM = 0, PC_ATTN, PC_LN, PC_EMBED, PC_HEAD, PC_SAMPLE, PC_C
 struct DenseW {   // y = x W^T + b ; W bf16 [N][K], b fp32 [N].  Strict precision mode: w is [N][3K], each row the
   bf16_t* w = nullptr;   // K-concatenated split-bf16 operand [hi | lo | hi] (hi = bf16(W), lo = bf16(W - hi))
   float* b = nullptr;
-  float* colsum = nullptr;   // LayerNorm-folded copies only: s_n = sum_k w[n][k] (of the bf16 values)
   int N = 0, K = 0;
 };
-// y = LN(x; gamma, beta) W^T + b  ==  rstd (x W'^T - mean s) + b'   with W' = bf16(scale W gamma), s_n = sum_k W'[n][k],
-// b'_n = scale (b_n + sum_k W[n][k] beta_k).  Host side (fp64 sums); wf = fp32 scale W gamma (rounded to bf16 at upload).
-void fold_ln_into_weights(const float* W, const float* b, const float* gamma, const float* beta, float scale, int N, int K,
-                          float* wf, float* bprime, float* colsum);
 struct LnW { float* g = nullptr; float* b = nullptr; };
 
 struct EsmLayer {
   LnW ln1, ln2;
   DenseW qkv, out, fc1, fc2;
-  DenseW qkv_f, fc1_f;     // LayerNorm-folded copies (bf16 mode): ln1 folded into qkv, ln2 into fc1
 };
 struct MsaLayer {
   LnW ln_row, ln_col, ln_ffn;
@@ -70,10 +64,12 @@ struct Engine {
   // workspace (grow-only)
   DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
-  DevBuf ln_stats;                         // folded LayerNorm: per row and 64-column segment (sum x, sum x^2) of the residual stream
-  bool fold_ln = false;                    // engine option (bf16 mode; PGIBBS_LN_FOLD=0 switches it off)
-  bool fold_active(int64_t rows) const { return fold_ln && rows > 2048; }    // taken on the JOB's token rows (shard invariance): the many-chain regime
-  DevBuf ln_center;                        // folded LayerNorm: two arrays [Mp] of row means (operand centring), alternating
+  DevBuf ln_counters;                      // LayerNorm inside the residual GEMMs: arrival counters per row panel (self-resetting)
+  bool prof_split_ln = false;              // profiling aid: keep LayerNorm a separate launch (time split per class)
+  bool fuse_ln = false;                    // PGIBBS_LN_FUSE=1: LayerNorm inside the residual GEMMs (bit-identical results; measured slower)
+  // x (+)= a W^T + b, then h = LayerNorm(x; ln): one launch when the big-tile kernel takes the shape, else GEMM + LayerNorm kernel
+  int resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
+                    float* ws = nullptr, size_t ws_bytes = 0);
   DevBuf tmp_idx, tmp_out;                 // batched generate_single on small MSAs: one template's step table / outputs
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask

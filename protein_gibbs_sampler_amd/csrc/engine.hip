@@ -9,8 +9,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <thread>
-
 #include "gemm_epilogue.h"
 
 namespace pg {
@@ -96,38 +94,11 @@ Engine::~Engine() {
   if (device >= 0) (void)hipSetDevice(device);
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
-                    &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &ln_stats, &ln_center, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
+                    &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &ln_counters, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
   for (DevBuf* b : bufs) b->release();
   prof.destroy();
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
   if (own_stream) (void)hipStreamDestroy(own_stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// LayerNorm folded into the following projection (gemm_epilogue.h): host-side preparation of W', s, b'
-// ------------------------------------------------------------------------------------------------
-void fold_ln_into_weights(const float* W, const float* b, const float* gamma, const float* beta, float scale, int N, int K,
-                          float* wf, float* bprime, float* colsum) {
-  auto rows = [&](int n0, int n1) {
-    for (int n = n0; n < n1; ++n) {
-      const float* w = W + (size_t)n * K;
-      float* o = wf + (size_t)n * K;
-      double s = 0.0, bb = 0.0;
-      for (int k = 0; k < K; ++k) {
-        const float v = scale * w[k] * gamma[k];
-        o[k] = v;
-        s += (double)bf16_to_f32(f32_to_bf16(v));     // the value the MFMA multiplies with
-        bb += (double)w[k] * (double)beta[k];
-      }
-      colsum[n] = (float)s;
-      bprime[n] = scale * (float)((double)b[n] + bb);
-    }
-  };
-  const int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-  if (nt <= 1 || (size_t)N * K < (1u << 20)) { rows(0, N); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; ++t) th.emplace_back(rows, (int)((int64_t)N * t / nt), (int)((int64_t)N * (t + 1) / nt));
-  for (auto& t : th) t.join();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -181,42 +152,6 @@ struct Uploader {
     out.K = K;
     return true;
   }
-  // LayerNorm-folded copy of `dense` (bf16 mode): W' bf16 [N][K], b' and the column sums fp32 [N]
-  bool dense_folded(DenseW& out, const std::vector<std::string>& prefixes, const std::vector<float>& scales, int n_each, int K,
-                    const std::string& ln_prefix) {
-    const int parts = (int)prefixes.size();
-    const int64_t N = (int64_t)n_each * parts;
-    const float* g = tm->get(ln_prefix + ".weight", K, err);
-    const float* bt = g ? tm->get(ln_prefix + ".bias", K, err) : nullptr;
-    if (!g || !bt) return false;
-    std::vector<float> wf((size_t)N * K), bp((size_t)N), cs((size_t)N);
-    for (int p = 0; p < parts; ++p) {
-      const float* w = tm->get(prefixes[p] + ".weight", (int64_t)n_each * K, err);
-      const float* b = w ? tm->get(prefixes[p] + ".bias", n_each, err) : nullptr;
-      if (!w || !b) return false;
-      fold_ln_into_weights(w, b, g, bt, scales[p], n_each, K, wf.data() + (size_t)p * n_each * K, bp.data() + (size_t)p * n_each,
-                           cs.data() + (size_t)p * n_each);
-    }
-    void *dw = nullptr, *db = nullptr, *dc = nullptr, *tmp = nullptr;
-    if (hipMalloc(&dw, (size_t)N * K * 2) != hipSuccess || hipMalloc(&db, (size_t)N * 4) != hipSuccess ||
-        hipMalloc(&dc, (size_t)N * 4) != hipSuccess || hipMalloc(&tmp, (size_t)N * K * 4) != hipSuccess) { err = "hipMalloc failed for folded " + prefixes[0]; return false; }
-    e->owned.push_back(dw);
-    e->owned.push_back(db);
-    e->owned.push_back(dc);
-    bool ok = hipMemcpy(tmp, wf.data(), (size_t)N * K * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              launch_f32_to_bf16(e->stream, (const float*)tmp, (bf16_t*)dw, N * K, 1.f) == 0 &&
-              hipStreamSynchronize(e->stream) == hipSuccess &&
-              hipMemcpy(db, bp.data(), (size_t)N * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(dc, cs.data(), (size_t)N * 4, hipMemcpyHostToDevice) == hipSuccess;
-    (void)hipFree(tmp);
-    if (!ok) { err = "upload failed for folded " + prefixes[0]; return false; }
-    out.w = (bf16_t*)dw;
-    out.b = (float*)db;
-    out.colsum = (float*)dc;
-    out.N = (int)N;
-    out.K = K;
-    return true;
-  }
   bool ln(LnW& out, const std::string& prefix, int d) {
     out.g = f32(prefix + ".weight", d);
     out.b = out.g ? f32(prefix + ".bias", d) : nullptr;
@@ -249,9 +184,10 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
   Uploader up{this, &tm, ""};
   const int d = cfg.d_model, f = cfg.d_ffn, V = cfg.vocab;
   {
-    // LayerNorm folded into the GEMMs around it: bf16 mode, 256-multiple widths (the big-tile kernels), ESM-1b trunk
-    const char* ev = getenv("PGIBBS_LN_FOLD");
-    fold_ln = (ev ? atoi(ev) != 0 : true) && !strict() && cfg.arch == PG_ARCH_ESM1B && d % 256 == 0 && f % 256 == 0 && d <= 64 * kLnStatPitch;
+    // LayerNorm inside the residual GEMMs (gemm_epilogue.h): bit-identical with the stand-alone kernel, but measured SLOWER
+    // (config 2: 91.5 vs 87.8 ms per iteration; config 4: 153.7 vs 150.4) -- off unless PGIBBS_LN_FUSE=1
+    const char* ev = getenv("PGIBBS_LN_FUSE");
+    fuse_ln = ev ? atoi(ev) != 0 : false;
   }
   const float qs = 0.125f;  // head_dim^-0.5 = 64^-0.5, folded into W_q and b_q (exact in bf16)
   bool ok = true;
@@ -273,11 +209,6 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
       ok = ok && up.ln(L.ln2, p + "final_layer_norm", d);
       ok = ok && up.dense(L.fc1, {p + "fc1"}, {1.f}, f, d);
       ok = ok && up.dense(L.fc2, {p + "fc2"}, {1.f}, d, f);
-      if (fold_ln) {
-        ok = ok && up.dense_folded(L.qkv_f, {p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"}, {qs, 1.f, 1.f}, d, d,
-                                   p + "self_attn_layer_norm");
-        ok = ok && up.dense_folded(L.fc1_f, {p + "fc1"}, {1.f}, f, d, p + "final_layer_norm");
-      }
     }
   } else if (ok) {
     ok = ok && (msa_pos = up.f32("msa_position_embedding", (int64_t)cfg.max_msa_rows * d));
@@ -387,53 +318,20 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   bf16_t* CTX = ctx.as<bf16_t>();
   bf16_t* FFN = ffn.as<bf16_t>();
   const float eps = cfg.layer_norm_eps;
-  // LayerNorm folded into the GEMMs around it (gemm_epilogue.h): from layer 0's out-projection on, the residual GEMMs also emit
-  // the bf16 copy of the updated rows (into `h`, which the LayerNorm kernel used to write) and per-row partial sums, and the
-  // QKV / fc1 GEMMs normalise in their epilogue.  Decided on the JOB's token rows, so every shard takes the same path.
-  const bool fold = fold_active(batch_rows);
   // <= 256 rows: 64-row tiles, <= 48 rows the weight-streaming GEMM (buffers stay 256-padded) -- the latter not for a tiny shard
-  // of a big job (sel_gemm_rows); the folded path always runs whole 256-row panels
-  const int Mi = fold ? (int)Mp : sel_gemm_rows(M, Mp);
-  if (fold && ((rc = ln_stats.ensure((size_t)Mp * kLnStatPitch * 2 * 4, stream)) || (rc = ln_center.ensure((size_t)2 * Mp * 4, stream)))) return rc;
-  EpiAux aux_p{}, aux_c{};
-  static const int fold_flags = [] { const char* e = getenv("PGIBBS_FOLD_FLAGS"); return e ? atoi(e) : 0; }();
-  aux_p.flags = aux_c.flags = fold_flags;
-  aux_p.xb = Hh;
-  aux_p.stats_out = ln_stats.as<float>();
-  aux_c.stats_in = ln_stats.as<float>();
-  aux_c.inv_n = 1.0f / (float)d;
-  aux_c.eps = eps;
-  // operand centring: array `cur` holds the c_row the next producer centres with (zeros before the first folded LayerNorm);
-  // a consumer reads it and publishes its rows' means into the other array, which then becomes `cur`
-  float* center[2] = {ln_center.as<float>(), ln_center.as<float>() + Mp};
-  int cur = 0;
-  if (fold) PG_HIP(hipMemsetAsync(center[0], 0, (size_t)Mp * 4, stream));
-  auto consumer_aux = [&](const float* colsum) {
-    aux_c.colsum = colsum;
-    aux_c.center_in = center[cur];
-    aux_c.center_out = center[cur ^ 1];
-    cur ^= 1;
-    return &aux_c;
-  };
-  auto producer_aux = [&]() {
-    aux_p.center_in = center[cur];
-    return &aux_p;
-  };
+  // of a big job (sel_gemm_rows)
+  const int Mi = sel_gemm_rows(M, Mp);
 
   rc = timed(PC_EMBED, [&] {
     return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
                            cfg.mask_idx, cfg.token_dropout, 0, eps);
   });
   if (rc) return rc;
+  if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, esm_layers[0].ln1.g, esm_layers[0].ln1.b, Hh, M, d, eps); }))) return rc;
   for (int l = 0; l < cfg.n_layers; ++l) {
     const EsmLayer& L = esm_layers[l];
-    if (fold && l > 0) {
-      const EpiAux* ac = consumer_aux(L.qkv_f.colsum);
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_big(stream, Hh, L.qkv_f.w, L.qkv_f.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16_LNF, ac); }))) return rc;
-    } else {
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, Hh, M, d, eps); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
-    }
+    // Hh holds LN1(x): written by the previous layer's fc2 launch (or the LayerNorm kernel) -- see resid_gemm_ln
+    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if ((rc = timed(PC_ATTN, [&] { return launch_attention_bf16(stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: only the selected rows are ever read again -> gather them and finish the layer on n_sel rows
@@ -454,22 +352,43 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
     }
-    if (fold) {
-      const bool last = l == cfg.n_layers - 1;        // nothing consumes the last layer's operand copy
-      const EpiAux* ap = producer_aux();
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_big(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID_LN, ap); }))) return rc;
-      const EpiAux* ac = consumer_aux(L.fc1_f.colsum);
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_big(stream, Hh, L.fc1_f.w, L.fc1_f.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU_LNF, ac); }))) return rc;
-      ap = producer_aux();
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_big(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, last ? EPI_F32_RESID : EPI_F32_RESID_LN, last ? nullptr : ap); }))) return rc;
-      continue;
-    }
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
-    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, Hh, M, d, eps); }))) return rc;
+    if ((rc = resid_gemm_ln(CTX, L.out, X, Mi, M, d, L.ln2, Hh))) return rc;                       // x += out_proj(ctx); h = LN2(x)
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+    if (l + 1 < cfg.n_layers) {                                                                    // x += fc2(ffn); h = LN1 of the next layer
+      if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, esm_layers[l + 1].ln1, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes))) return rc;
+    } else {
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+    }
   }
   return PG_OK;
+}
+
+// x[M_rows][d] += a[M_rows][K] W^T + b, then h = LayerNorm(x; ln) as the next GEMM's bf16 operand.  Big batches: ONE launch --
+// the residual GEMM's workgroup that completes a row panel normalises it (gemm_epilogue.h) --, otherwise the GEMM the dispatch
+// picks followed by the LayerNorm kernel.  Both forms run the same per-row LayerNorm code on the same fp32 rows: identical bits,
+// so the choice is purely local (no shard-invariance concern).
+int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
+                          float* ws, size_t ws_bytes) {
+  const int d = W.N, K = W.K;
+  const bool big = fuse_ln && !prof_split_ln && M_rows % 256 == 0 && d % 256 == 0 && K >= 128 && K % 64 == 0 &&
+                   (long)(M_rows / 256) * (d / 256) >= 128 &&      // the shapes launch_gemm_bf16 gives to the big-tile kernels
+                   gemm_big_can_fuse_ln(M_rows, d, K);              // ... with every row panel's tiles on one XCD
+  if (big) {
+    int rc = ln_counters.ensure((size_t)(M_rows / 64 + 8) * 4, stream);
+    if (rc) return rc;
+    EpiAux aux{};
+    aux.h = h;
+    aux.gamma = ln.g;
+    aux.beta = ln.b;
+    aux.counters = ln_counters.as<int>();
+    aux.eps = cfg.layer_norm_eps;
+    static const int ln_flags = [] { const char* e = getenv("PGIBBS_LN_FLAGS"); return e ? atoi(e) : 0; }();
+    aux.flags = ln_flags;
+    return timed(PC_GEMM, [&] { return launch_gemm_big(stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID_LN, &aux); });
+  }
+  int rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
+  if (rc) return rc;
+  return timed(PC_LN, [&] { return launch_layernorm_bf16(stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps); });
 }
 
 // LM head evaluated ONLY at the selected rows: emb_layer_norm_after -> dense -> GELU ->
@@ -646,10 +565,11 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   });
   if (rc) return rc;
   const SeqLayout col = {C, R * C, 1, C};                   // column c of msa b: rows (b*R + r)*C + c
+  // Hh always holds the LayerNorm the next projection reads: written by the previous residual GEMM's launch (resid_gemm_ln)
+  if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, msa_layers[0].ln_row.g, msa_layers[0].ln_row.b, Hh, M, d, eps); }))) return rc;
   for (int l = 0; l < cfg.n_layers; ++l) {
     const MsaLayer& L = msa_layers[l];
     // tied row attention
-    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_row.g, L.ln_row.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if (C <= 576) {
       float* part = nullptr;
@@ -672,9 +592,8 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       });
       if (rc) return rc;
     }
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.row_out.w, L.row_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+    if ((rc = resid_gemm_ln(CTX, L.row_out, X, Mi, M, d, L.ln_col, Hh))) return rc;                 // x += row_out(ctx); h = LN_col(x)
     // column attention (q pre-scaled by dh^-0.5 in the weights)
-    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_col.g, L.ln_col.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if ((rc = timed(PC_ATTN, [&] { return launch_attention_seq_bf16(stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
@@ -696,11 +615,14 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
     }
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.col_out.w, L.col_out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+    if ((rc = resid_gemm_ln(CTX, L.col_out, X, Mi, M, d, L.ln_ffn, Hh))) return rc;                 // x += col_out(ctx); h = LN_ffn(x)
     // feed forward
-    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln_ffn.g, L.ln_ffn.b, Hh, M, d, eps); }))) return rc;
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+    if (l + 1 < cfg.n_layers) {                                                                      // x += fc2(ffn); h = LN_row of the next layer
+      if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, msa_layers[l + 1].ln_row, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes))) return rc;
+    } else {
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+    }
   }
   return PG_OK;
 }

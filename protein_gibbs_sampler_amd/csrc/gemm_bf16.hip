@@ -165,8 +165,9 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(rsrc_t rs, int voff, int soff) {
 // Stores keep the row step in the VGPR offset: with an SGPR soffset the compiler's hazard recogniser assumes a 128-bit
 // store's data registers may be overwritten by the very next VALU instruction, and on gfx950 that corrupted the last
 // dword of the stored row (seen as wrong .w components in lanes 12-15 of each 16) -- with soffset = 0 it pads the hazard.
-__device__ __forceinline__ void buf_store_f32x4(f32x4 v, rsrc_t rs, int voff, int row_off) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, PG_EPI_AUX);
+__device__ __forceinline__ void buf_store_f32x4(f32x4 v, rsrc_t rs, int voff, int row_off, bool stream = true) {
+  if (stream) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, PG_EPI_AUX);
+  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, 0);
 }
 
 template <int EPI, bool NO_STORE = false>
@@ -225,20 +226,6 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       return;
     }
     if (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN) {
-      // EPI_F32_RESID_LN (LayerNorm folded into the neighbouring GEMMs, gemm_epilogue.h): a lane's four values are columns
-      // 4*lane .. of the row, so the 16 lanes of a DPP row hold one 64-column segment -- its partial sums and the bf16 copy
-      // of the updated row leave from here too.
-      // c_row of this wave's 32 rows: lane l < 16 holds the one of phase 0's row l, lanes 16-31 phase 1's
-      float cv = 0.f;
-      if (EPI == EPI_F32_RESID_LN) cv = aux.center_in[(lane < 16 ? grow(0) : grow(1) - 16) + (lane & 31)];
-      auto ln_out = [&](const f32x4 xn, int row, float c) {
-        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-        const uint2 pk = ln_operand_pack(xn, c);
-        u32x2_t* dst = (u32x2_t*)(aux.xb + (size_t)row * ldo + n0 + lane * 4);
-        if (aux.flags & 1) __builtin_nontemporal_store((u32x2_t){pk.x, pk.y}, dst);
-        else *dst = (u32x2_t){pk.x, pk.y};
-        ln_partial_store(xn, aux.stats_out + ((size_t)row * kLnStatPitch + (n0 >> 6) + (lane >> 4)) * 2, lane);
-      };
       // Row-shaped accesses as buffer ops: wave-uniform row base in the resource, the row step in an SGPR offset, one
       // VGPR (lane*16) for all 64 accesses -- 64-bit per-row VGPR addresses would not leave room for 32 rows in flight.
       const rsrc_t rs0 = row_rsrc((float*)out + (size_t)grow(0) * ldo + n0);
@@ -258,9 +245,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        const f32x4 xn = r0[it] + v;
-        buf_store_f32x4(xn, rs0, voff, it * rstep);
-        if (EPI == EPI_F32_RESID_LN) ln_out(xn, grow(0) + it, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), it)));
+        buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep, !(EPI == EPI_F32_RESID_LN && (aux.flags & 1)));
       }
       __syncthreads();
       stage(1);
@@ -269,9 +254,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        const f32x4 xn = r1[it] + v;
-        buf_store_f32x4(xn, rs1, voff, it * rstep);
-        if (EPI == EPI_F32_RESID_LN) ln_out(xn, grow(1) + it, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cv), 16 + it)));
+        buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep, !(EPI == EPI_F32_RESID_LN && (aux.flags & 1)));
       }
       return;
     }
@@ -346,8 +329,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
   if (ABL == 0 && (int)blockIdx.x < n_tail) {
-    const int tn64 = tiles_n * 4, bt = blockIdx.x;
-    gemm_tail_tile64<8, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, nullptr, aux);
+    // workgroup b runs on XCD b % 8: all column tiles of a 64-row block go to one XCD (its L2 is where a fused LayerNorm meets
+    // the rows, gemm_epilogue.h) whenever the row blocks divide by 8 (tail rows are multiples of 256: at least by 4)
+    const int tn64 = tiles_n * 4, bt = blockIdx.x, n_rb = n_tail / tn64;
+    int rb, tn;
+    if ((n_rb & 7) == 0) { const int j = bt >> 3; rb = (j / tn64) * 8 + (bt & 7); tn = j % tn64; }
+    else { rb = bt / tn64; tn = bt % tn64; }
+    gemm_tail_tile64<8, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + rb * 64, tn * 64, smem,
+                             n_tiles / tiles_n + rb, aux);             // LayerNorm counters: after the panels of the big tiles
     return;
   }
 
@@ -479,6 +468,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     return;
   }
   epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo, aux);
+  if (EPI == EPI_F32_RESID_LN) {     // the last of the panel's column tiles normalises its 256 rows (gemm_epilogue.h)
+    __syncthreads();                 // the staging LDS is free (flag word)
+    ln_when_panel_complete<8>(aux, tile_m, tiles_n, (const float*)out + (size_t)m0 * ldo, m0, 256, ldo, (int*)smem);
+  }
 }
 
 // Measured alternatives that were NOT faster on MI355X and were removed again (QKV GEMM, M=66048 N=3840 K=1280, steady-state
@@ -561,6 +554,36 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   return 0;
 }
 
+// geometry of a big-batch launch: m-panels of 256 x 256 tiles + rows of 64 x 64 tail tiles (launch_gemm_big)
+struct BigGeom { int m_main, tail_rows, gm; };
+static BigGeom big_geometry(int M, int N, int K) {
+  static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+  static const int tail_on = [] { const char* e = getenv("PGIBBS_GEMM_TAIL"); return e ? atoi(e) : 1; }();
+  static const int tail_max = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_MAX"); return e ? atoi(e) : 4; }();   // tail tiles per CU at most
+  static const int gm_env = [] { const char* e = getenv("PGIBBS_GEMM_GM"); return e ? atoi(e) : 0; }();
+  const int tiles_n = N / 256, tiles_m = M / 256;
+  const long t256 = (long)tiles_m * tiles_n, full = t256 / n_cu, frac = t256 - full * n_cu;
+  BigGeom g{tiles_m, 0, gm_env ? (gm_env <= 2 ? gm_env : 4) : (K >= 4096 ? 2 : 4)};      // the GM the launchers instantiate
+  if (tail_on && frac > 0) {
+    const int mm = (int)(full * n_cu / tiles_n);             // m-panels that fill whole rounds (0: less than one round of big tiles)
+    const long n_tail = (long)(tiles_m - mm) * 4 * (N / 64);
+    if (n_tail <= (long)tail_max * n_cu) { g.m_main = mm; g.tail_rows = (tiles_m - mm) * 256; }
+  }
+  return g;
+}
+// EPI_F32_RESID_LN needs every row panel's column tiles on one XCD (gemm_epilogue.h): XCD x owns the contiguous tile range
+// [x q + min(x, r), ...) of the grouped order, a group being gm m-panels x all n-tiles -- so every range must begin on a group
+// boundary; tail row blocks must divide by 8.
+bool gemm_big_can_fuse_ln(int M, int N, int K) {
+  if (M % 256 || N % 256 || K % 64 || K < 128 || M < 256 || N > 2048) return false;
+  const BigGeom g = big_geometry(M, N, K);
+  const int tiles_n = N / 256, n_tiles = g.m_main * tiles_n, gsz = g.gm * tiles_n;
+  const int q = n_tiles >> 3, r = n_tiles & 7;
+  for (int x = 1; x < 8; ++x)
+    if ((x * q + (x < r ? x : r)) % gsz) return false;
+  return ((g.tail_rows / 64) & 7) == 0;
+}
+
 // The big-batch GEMM: whole rounds of 256 x 256 tiles (one per CU) plus, in the SAME grid, 64 x 64 tail tiles for the rows
 // beyond the last full round when that round would be mostly empty (gemm_epilogue.h).  Kernel per epilogue: the 16-wave kernel
 // for the bf16 outputs (QKV projections: 3.5-4 % faster there; fc1: its one-pass GELU epilogue is 0.03 ms shorter per launch),
@@ -569,21 +592,13 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                     int ldw, int ldo, int epi, const EpiAux* aux) {
   if (M % 256 || N % 256 || K % 64 || K < 128 || M < 256) return fail(1, "gemm_big: shape");
-  static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-  static const int tail_on = [] { const char* e = getenv("PGIBBS_GEMM_TAIL"); return e ? atoi(e) : 1; }();
-  static const int tail_max = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_MAX"); return e ? atoi(e) : 4; }();   // tail tiles per CU at most
   static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? 16 : 0); }();
-  const int tiles_n = N / 256, tiles_m = M / 256;
-  const long t256 = (long)tiles_m * tiles_n, full = t256 / n_cu, frac = t256 - full * n_cu;
-  int m_main = tiles_m, tail_rows = 0;
-  if (tail_on && frac > 0) {
-    const int mm = (int)(full * n_cu / tiles_n);             // m-panels that fill whole rounds (0: less than one round of big tiles)
-    const long n_tail = (long)(tiles_m - mm) * 4 * (N / 64);
-    if (n_tail <= (long)tail_max * n_cu) { m_main = mm; tail_rows = (tiles_m - mm) * 256; }
-  }
-  const bool lnf = epi == EPI_BF16_LNF || epi == EPI_BF16_GELU_LNF;
-  const bool bf16out = epi == EPI_BF16 || epi == EPI_BF16_GELU || lnf;
-  const bool use16 = lnf || (epi != EPI_F32_RESID_LN && (big == 16 || (big == -1 && bf16out)));
+  const BigGeom geo = big_geometry(M, N, K);
+  const int m_main = geo.m_main, tail_rows = geo.tail_rows;
+  const bool bf16out = epi == EPI_BF16 || epi == EPI_BF16_GELU;
+  const bool use16 = epi != EPI_F32_RESID_LN && (big == 16 || (big == -1 && bf16out));
+  if (epi == EPI_F32_RESID_LN && (!aux || N != ldo || !gemm_big_can_fuse_ln(M, N, K)))
+    return fail(1, "gemm_big: the LayerNorm epilogue needs its operands, whole rows (N == ldo) and a row panel's tiles on one XCD");
   if (use16) return launch_gemm_w16(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows, aux);
   return launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows, aux);
 }

@@ -2,6 +2,7 @@
 // (one definition for all kernels) and the LDS-staged epilogue of the 256 x 256 tiles with 4 or 16 waves.
 #pragma once
 #include "kernels.h"
+#include "ln_row.h"
 
 namespace pg {
 
@@ -59,94 +60,53 @@ __device__ __forceinline__ uint32_t gelu_bf16out_pack2(float x0, float x1) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm folded into the GEMMs around it (bf16 mode, big batches; engine.hip `fold_ln`).
-//   producer (out-proj / fc2, EPI_F32_RESID_LN): x += acc + bias as before, and additionally (a) a bf16 copy of the updated
-//     residual row -- the NEXT GEMM's operand -- and (b) per row and per 64-column segment the partial sums (sum x, sum x^2);
-//   consumer (QKV / fc1, EPI_BF16_LNF / EPI_BF16_GELU_LNF): W' = bf16(W . gamma) is multiplied with the RAW bf16 row and the
-//     normalisation is applied to the accumulator:  LN(x) . W^T + b = rstd (x . W'^T - mean . s) + b',
-//     s_n = sum_k W'[n][k], b'_n = b_n + sum_k W[n][k] beta_k (host, at upload).
-// This removes the LayerNorm kernel (one fp32 read + one bf16 write of the whole residual stream per LayerNorm) for one extra
-// bf16 row store in the producer's epilogue.  Every piece below is shared by the 256 x 256 tiles and the 64 x 64 tail tiles, so
-// a row gets bit-identical statistics, operand row and output whichever tile shape computes it (shard invariance).
+// LayerNorm inside the residual GEMM (EPI_F32_RESID_LN).  x += ctx W^T + b is followed, in the forward pass, by h = LN(x): a
+// kernel that re-reads from HBM the 338 MB the GEMM has just written (config 2: 85 us, 66 times per iteration, at the HBM
+// roofline -- pure avoidable traffic).  A row can only be normalised when all of its column tiles are done, so every workgroup,
+// after storing its tile, counts itself into a per-row-panel counter; the LAST one to arrive for a panel normalises that
+// panel's rows -- one wave per row, the very code of the stand-alone kernel (ln_row.h), so h is bit-identical with the unfused
+// path and results do not depend on which workgroup happens to be last, nor on whether a launch fuses at all.
+// Coherence without cache maintenance: the launcher fuses only when all column tiles of a panel run on ONE XCD (the grouped
+// tile order puts them there; checked on the host, else the LayerNorm kernel follows as before).  The XCD's CUs share its L2,
+// which is therefore the coherence point: a writer's stores are acknowledged by L2 (s_waitcnt vmcnt(0)) before it counts
+// itself in, the counter is an L2 atomic, and the normalising workgroup reads the rows with sc0 loads (past its own L1).  An
+// agent-scope release / acquire pair instead (buffer_wbl2 / buffer_inv sc1 per tile) writes back and invalidates the whole L2
+// under the other CUs' main loops: measured 121 vs 90 ms per iteration.
+// Counters reset themselves (the last arriver stores 0), so a zero-filled array serves every launch.
 // ---------------------------------------------------------------------------------------------------------------------
-// Centring: the operand copy is bf16(x - c_row) with c_row = the row's mean at the PREVIOUS LayerNorm (LayerNorm is invariant
-// under a per-row shift, so the consumer only replaces mean by mean - c_row): the bf16 rounding then acts on a row whose mean is
-// ~0, as it does on the LayerNorm kernel's output, instead of on |x| -- without it the folded form loses accuracy when a row's
-// mean is not small against its spread.  Consumers publish their rows' means (tile column 0 only) for the next producer;
-// two arrays alternate so that nobody reads what a neighbour tile of the same launch writes.
-constexpr int kLnStatPitch = 32;     // partial-sum slots per row (64-column segments: d_model <= 2048); unused slots stay zero
 struct EpiAux {
-  bf16_t* xb;              // producer: bf16 copy of the updated, centred rows, [M][ldo]
-  float* stats_out;        // producer: partial sums [M][kLnStatPitch][2]
-  const float* stats_in;   // consumer: the operand rows' partial sums [M][kLnStatPitch][2]
-  const float* colsum;     // consumer: s_n [N]
-  const float* center_in;  // both: c_row [M] the operand copy was / is to be centred with
-  float* center_out;       // consumer: the rows' means, for the next producer
-  float inv_n, eps;        // consumer: 1 / d_model, LayerNorm epsilon
-  int flags;               // experiments (PGIBBS_FOLD_FLAGS): 1 = non-temporal operand-copy stores, 2 = timing only: no statistics loads
+  bf16_t* h;               // LayerNorm output rows [M][d] bf16 (the next GEMM's operand)
+  const float* gamma;      // the FOLLOWING LayerNorm's weight / bias [d]
+  const float* beta;
+  int* counters;           // one per 256-row panel of 256 x 256 tiles, then one per 64-row block of tail tiles; zero between launches
+  float eps;
+  int flags;               // experiments (PGIBBS_LN_FLAGS): 1 = the residual rows leave with ordinary (not streaming) stores
 };
 
-#define PG_DPP_ADD(v, ctrl) \
-  __fadd_rn((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true)))
-// all-reduce over the 16 lanes of a DPP row (= one 64-column segment, 4 columns per lane), fixed tree:
-// lane ^ 1 (quad_perm [1,0,3,2]), lane ^ 2 (quad_perm [2,3,0,1]), the other quad of the half (row_half_mirror), the other half
-// (row_mirror); fp32 addition is commutative, so all 16 lanes end with the same bits
-__device__ __forceinline__ float seg16_sum(float v) {
-  v = PG_DPP_ADD(v, 0xB1);
-  v = PG_DPP_ADD(v, 0x4E);
-  v = PG_DPP_ADD(v, 0x141);
-  v = PG_DPP_ADD(v, 0x140);
-  return v;
-}
-// x = 4 consecutive columns of the updated residual row held by this lane; seg_stats = &stats[(row * kLnStatPitch + segment) * 2]
-__device__ __forceinline__ void ln_partial_store(const f32x4 x, float* seg_stats, int lane) {
-  float s1 = __fadd_rn(__fadd_rn(x[0], x[1]), __fadd_rn(x[2], x[3]));
-  float s2 = __fadd_rn(__fmaf_rn(x[0], x[0], __fmul_rn(x[1], x[1])), __fmaf_rn(x[2], x[2], __fmul_rn(x[3], x[3])));
-  s1 = seg16_sum(s1);
-  s2 = seg16_sum(s2);
-  if ((lane & 15) == 0) *(float2*)seg_stats = make_float2(s1, s2);
-}
-// (mean, rstd) of a row from its partial sums: all kLnStatPitch slots (the unused ones hold zeros), sixteen independent 16-B
-// loads issued together -- a loop over the used slots would serialise as many memory round trips in the tile's prologue --
-// summed in slot order
-__device__ __forceinline__ float2 ln_row_stats(const float* part, float inv_n, float eps) {
-  float4 q[kLnStatPitch / 2];
-#pragma unroll
-  for (int i = 0; i < kLnStatPitch / 2; ++i) q[i] = ((const float4*)part)[i];
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < kLnStatPitch / 2; ++i) {
-    s1 = __fadd_rn(__fadd_rn(s1, q[i].x), q[i].z);
-    s2 = __fadd_rn(__fadd_rn(s2, q[i].y), q[i].w);
-  }
-  const float mean = __fmul_rn(s1, inv_n);
-  const float var = fmaxf(__fmaf_rn(-mean, mean, __fmul_rn(s2, inv_n)), 0.f);
-  return make_float2(mean, __frsqrt_rn(__fadd_rn(var, eps)));
-}
-// consumer prologue for one operand row: its (mean - c_row, rstd); the tile column 0 also publishes the mean
-__device__ __forceinline__ float2 ln_consumer_row(const EpiAux& aux, int row, bool publish) {
-  if (aux.flags & 2) return make_float2(0.f, 1.f);
-  const float2 st = ln_row_stats(aux.stats_in + (size_t)row * kLnStatPitch * 2, aux.inv_n, aux.eps);
-  const float c = aux.center_in[row];
-  if (publish) aux.center_out[row] = st.x;
-  return make_float2(__fsub_rn(st.x, c), st.y);
-}
-// producer: the centred bf16 operand copy of 4 consecutive columns
-__device__ __forceinline__ uint2 ln_operand_pack(const f32x4 xn, float c) {
-  uint2 pk;
-  pk.x = pack_bf16x2(__fsub_rn(xn[0], c), __fsub_rn(xn[1], c));
-  pk.y = pack_bf16x2(__fsub_rn(xn[2], c), __fsub_rn(xn[3], c));
-  return pk;
-}
-__device__ __forceinline__ float ln_fold_apply(float acc, float2 st, float colsum, float bias) {
-  return __fmaf_rn(st.y, __fmaf_rn(-st.x, colsum, acc), bias);
-}
 template <int EPI> struct EpiTraits {
-  static constexpr bool lnf = EPI == EPI_BF16_LNF || EPI == EPI_BF16_GELU_LNF;
-  static constexpr bool bf16out = EPI == EPI_BF16 || EPI == EPI_BF16_GELU || lnf;
-  static constexpr bool gelu_bf16 = EPI == EPI_BF16_GELU || EPI == EPI_BF16_GELU_LNF;
+  static constexpr bool bf16out = EPI == EPI_BF16 || EPI == EPI_BF16_GELU;
+  static constexpr bool gelu_bf16 = EPI == EPI_BF16_GELU;
   static constexpr bool resid = EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN;
 };
+
+// Called by every thread of a workgroup after its tile's stores: counts the workgroup into counters[slot]; the workgroup that
+// completes the n_tiles of the row block normalises its n_rows rows (x_rows = first row of the block, row length d = ldo).
+template <int NW>
+__device__ __forceinline__ void ln_when_panel_complete(const EpiAux& aux, int slot, int n_tiles, const float* x_rows, int64_t row0,
+                                                       int n_rows, int d, int* flag /* LDS word */) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my stores of the residual tile are in the XCD's L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = __hip_atomic_fetch_add(aux.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == n_tiles - 1;
+    if (last) __hip_atomic_store(aux.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  ln_rows_l2<4>(x_rows, d, aux.h + (size_t)row0 * d, n_rows, wave, NW, d, aux.eps, aux.gamma, aux.beta, lane);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 64 x 64 "tail" tile computed by a whole 8- or 16-wave workgroup of the 256 x 256 kernels.  1290 tiles on 256 CUs are
@@ -160,16 +120,13 @@ template <int EPI> struct EpiTraits {
 template <int NW, int EPI>
 __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                  const float* __restrict__ bias, void* __restrict__ out, int K, int ldx, int ldw,
-                                                 int ldo, int m0, int n0, char* smem, float2* rowstat, const EpiAux& aux) {
+                                                 int ldo, int m0, int n0, char* smem, int ln_slot, const EpiAux& aux) {
   static_assert(NW == 8 || NW == 16, "tail tile: 8 or 16 waves");
   constexpr int STAGES = 8, STAGE_BYTES = 16384, PPW = 16 / NW, TM = 16 / NW;
   typedef EpiTraits<EPI> T;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nk = K / 64;
-
-  if (T::lnf && threadIdx.x < 64)       // (mean, rstd) of the tile's 64 operand rows; published by the K loop's barriers
-    rowstat[threadIdx.x] = ln_consumer_row(aux, m0 + threadIdx.x, n0 == 0);
 
   // piece p (0-7: X rows 8p .., 8-15: W rows 8(p-8) ..): wave w stages piece w, and with 8 waves also piece w + 8 -- so piece A is
   // an X piece for w < 8 and piece B (8 waves only) always a W piece.  (No arrays of buffer resources: the type is opaque.)
@@ -221,49 +178,18 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
   // lane holds D[n = ni*16 + fq*4 + r][m = (mi0 + j)*16 + fr], r = 0..3
   const int n_loc = ni * 16 + fq * 4;
   const float4 b4 = *(const float4*)(bias + n0 + n_loc);
-  if (EPI == EPI_F32_RESID_LN) {
-    // through LDS into row shape (16 lanes x 4 columns = the 64-column segment), then exactly the row code of the big tile
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m_loc = (mi0 + j) * 16 + fr;
-      *(float4*)(smem + m_loc * 256 + n_loc * 4) = make_float4(acc[j][0] + b4.x, acc[j][1] + b4.y, acc[j][2] + b4.z, acc[j][3] + b4.w);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 16 / NW; ++ps) {
-      const int row = (ps * NW + wave) * 4 + (lane >> 4), c = lane & 15;
-      const f32x4 v = *(const f32x4*)(smem + row * 256 + c * 16);
-      float* gp = (float*)out + (size_t)(m0 + row) * ldo + n0 + c * 4;
-      const f32x4 xn = *(const f32x4*)gp + v;
-      *(f32x4*)gp = xn;
-      *(uint2*)(aux.xb + (size_t)(m0 + row) * ldo + n0 + c * 4) = ln_operand_pack(xn, aux.center_in[m0 + row]);
-      ln_partial_store(xn, aux.stats_out + ((size_t)(m0 + row) * kLnStatPitch + (n0 >> 6)) * 2, lane);
-    }
-    return;
-  }
-  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (T::lnf) cs4 = *(const float4*)(aux.colsum + n0 + n_loc);
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m_loc = (mi0 + j) * 16 + fr;
-    float v0, v1, v2, v3;
-    if (T::lnf) {
-      const float2 st = rowstat[m_loc];
-      v0 = ln_fold_apply(acc[j][0], st, cs4.x, b4.x);
-      v1 = ln_fold_apply(acc[j][1], st, cs4.y, b4.y);
-      v2 = ln_fold_apply(acc[j][2], st, cs4.z, b4.z);
-      v3 = ln_fold_apply(acc[j][3], st, cs4.w, b4.w);
-    } else {
-      v0 = acc[j][0] + b4.x; v1 = acc[j][1] + b4.y; v2 = acc[j][2] + b4.z; v3 = acc[j][3] + b4.w;
-    }
+    float v0 = acc[j][0] + b4.x, v1 = acc[j][1] + b4.y, v2 = acc[j][2] + b4.z, v3 = acc[j][3] + b4.w;
     const size_t o = (size_t)(m0 + m_loc) * ldo + n0 + n_loc;
     if (T::bf16out) {
       uint2 p;
       p.x = T::gelu_bf16 ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
       p.y = T::gelu_bf16 ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
       *(uint2*)((bf16_t*)out + o) = p;
-    } else if (EPI == EPI_F32_RESID) {
+    } else if (T::resid) {
+      // x_old + (acc + bias), as the big tile's row-shaped epilogue adds them (fp32 addition commutes: same bits)
       float4* dst = (float4*)((float*)out + o);
       float4 r = *dst;
       r.x += v0; r.y += v1; r.z += v2; r.w += v3;
@@ -273,6 +199,8 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
       *(float4*)((float*)out + o) = make_float4(v0, v1, v2, v3);
     }
   }
+  if (EPI == EPI_F32_RESID_LN)     // the last of the row block's N / 64 tiles normalises its 64 rows
+    ln_when_panel_complete<NW>(aux, ln_slot, ldo / 64, (const float*)out + (size_t)m0 * ldo, m0, 64, ldo, (int*)smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -282,23 +210,12 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
 // ---------------------------------------------------------------------------------------------------------------------
 template <int EPI, int NW = 4, typename ElemF>
 __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int wave, int lane, int m0, int n0,
-                                            const float* __restrict__ bias, void* __restrict__ out, int ldo,
-                                            const float2* rowstat = nullptr, const EpiAux* aux = nullptr) {
+                                            const float* __restrict__ bias, void* __restrict__ out, int ldo) {
   constexpr int NE = 256 / NW;                   // elements per lane
   constexpr int RB = 256 / NW;                   // bf16 pass: tile rows owned by a wave
   constexpr int RF = 128 / NW;                   // fp32 passes: staged rows owned by a wave
   __syncthreads();                               // every wave is done with the operand ring
   if (EpiTraits<EPI>::bf16out) {
-    float2 st4[4];                               // folded LayerNorm: a lane's elements lie in four rows (e & 3)
-    if (EpiTraits<EPI>::lnf) {
-      static_assert(!EpiTraits<EPI>::lnf || NW == 16, "folded LayerNorm: element order of the 16-wave kernel");
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int row, n;
-        (void)elem(e, row, n);
-        st4[e] = rowstat[row];
-      }
-    }
     // one pass: the whole 256 x 256 bf16 tile (128 KB) as 256 rows of 512 B, chunk-swizzled by row.  The GELU of fc1 is
     // applied in registers on the way in: +0.053 ms on the fc1 launch against +0.085 for fp32 staging in two passes with the
     // GELU on the way out (the ping-pong kernel's form); splitting the tile in two halves so that the stores of one drain
@@ -308,17 +225,7 @@ __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int w
       int row, n;
       const f32x4 a = elem(e, row, n);
       const float4 b4 = *(const float4*)(bias + n0 + n);
-      float v0, v1, v2, v3;
-      if (EpiTraits<EPI>::lnf) {       // folded LayerNorm: rstd (acc - mean s_n) + b'_n
-        const float4 cs4 = *(const float4*)(aux->colsum + n0 + n);
-        const float2 st = st4[e & 3];
-        v0 = ln_fold_apply(a[0], st, cs4.x, b4.x);
-        v1 = ln_fold_apply(a[1], st, cs4.y, b4.y);
-        v2 = ln_fold_apply(a[2], st, cs4.z, b4.z);
-        v3 = ln_fold_apply(a[3], st, cs4.w, b4.w);
-      } else {
-        v0 = a[0] + b4.x; v1 = a[1] + b4.y; v2 = a[2] + b4.z; v3 = a[3] + b4.w;
-      }
+      const float v0 = a[0] + b4.x, v1 = a[1] + b4.y, v2 = a[2] + b4.z, v3 = a[3] + b4.w;
       uint2 p;
       if (EpiTraits<EPI>::gelu_bf16) {
         p.x = gelu_bf16out_pack2(v0, v1);

@@ -51,12 +51,11 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
                                                                int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
                                                                int tail_m0, EpiAux aux) {
   __shared__ __attribute__((aligned(16))) char smem[2 * W16_KSLOT];
-  __shared__ float2 rowstat[EpiTraits<EPI>::lnf ? 256 : 1];      // folded LayerNorm: (mean, rstd) of the tile's operand rows
 
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
   if (ABL == 0 && (int)blockIdx.x < n_tail) {
     const int tn64 = tiles_n * 4, bt = blockIdx.x;
-    gemm_tail_tile64<16, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, rowstat, aux);
+    gemm_tail_tile64<16, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, 0, aux);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -112,8 +111,6 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   dma_step(0);
-  if (EpiTraits<EPI>::lnf && threadIdx.x < 256)      // under the first DMA's latency; published by the K loop's barriers
-    rowstat[threadIdx.x] = ln_consumer_row(aux, m0 + threadIdx.x, n0 == 0);
   PG_W16_T(0);
   for (int t = 0; t < nk; ++t) {
     if ((ABL != 1 && ABL != 10) || t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of K-step t have landed
@@ -157,7 +154,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
     n_loc = wn * 64 + (e >> 2) * 16 + fq * 4;
     return acc[e >> 2][e & 3];
   };
-  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo, rowstat, &aux);
+  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -268,7 +265,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
     n_loc = wn * 64 + (e >> 2) * 16 + fq * 4;
     return acc[e >> 2][e & 3];
   };
-  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo, nullptr, nullptr);
+  tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
 // X3 [M][3K], W3 [N][3K] in the split operand layout; K = logical depth (a multiple of 32); M, N multiples of 256.
@@ -332,8 +329,6 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
   switch (epi) {
     PG_W16_CASE(EPI_BF16)
     PG_W16_CASE(EPI_BF16_GELU)
-    PG_W16_CASE(EPI_BF16_LNF)
-    PG_W16_CASE(EPI_BF16_GELU_LNF)
     PG_W16_CASE(EPI_F32_RESID)
     PG_W16_CASE(EPI_F32)
     PG_W16_CASE(EPI_F32_GELU)

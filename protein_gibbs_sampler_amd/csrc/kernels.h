@@ -13,9 +13,8 @@ struct SeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_GELU = 4,
        EPI_F32_PARTIAL = 5 /* internal: split-K partial sums, no bias */,
        EPI_SPLIT3_GELU = 6 /* strict mode fc1: erf-GELU, then the bf16 operand rows [lo | hi | hi] (ldo = 3 N) that fc2 reads; 16-wave kernel only */,
-       /* LayerNorm folded into the GEMMs around it (gemm_epilogue.h, EpiAux): */
-       EPI_F32_RESID_LN = 7 /* residual update + bf16 copy of the new rows + per-row partial (sum, sum of squares) */,
-       EPI_BF16_LNF = 8, EPI_BF16_GELU_LNF = 9 /* operand = raw bf16 rows, normalisation applied to the accumulator */ };
+       EPI_F32_RESID_LN = 7 /* residual update; the last column tile of a row panel to finish also writes h = LayerNorm(x) of the
+                               panel's rows (gemm_epilogue.h, EpiAux) -- the 8-wave tile kernel only */ };
 
 // out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M a multiple of 16 up to 256 rows, of 128 beyond; N a multiple of 64; K of 64
 // (activation buffers are padded to 256 rows: kernels may touch the padding rows of the last tile).
@@ -32,6 +31,8 @@ struct EpiAux;       // gemm_epilogue.h: operands of the LayerNorm-folding epilo
 // the big-batch GEMM: whole rounds of 256 x 256 tiles + 64 x 64 tail tiles in one grid (gemm_bf16.hip); M, N multiples of 256
 int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                     int ldw, int ldo, int epi, const EpiAux* aux = nullptr);
+// may a launch_gemm_big(..., EPI_F32_RESID_LN) of this shape normalise inside the GEMM? (every row panel's tiles on one XCD)
+bool gemm_big_can_fuse_ln(int M, int N, int K);
 // the 16-wave 256x256 tile kernel (gemm_w16.hip): M (may be 0 with tail_rows > 0), N multiples of 256, K a multiple of 64;
 // tail_rows rows of 64 x 64 tail tiles from row M on
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
