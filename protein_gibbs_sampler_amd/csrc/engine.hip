@@ -575,12 +575,12 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       float* part = nullptr;
       // few workgroups: give the kernel scratch for its split-R mode (decided on the job's batch: the split changes the
       // order of the sum over alignment rows, and a shard must compute what the whole batch would)
-      if (job_batch(B) * H * ((C + 63) / 64) < 384 && R >= 8) {
-        const size_t need = (size_t)B * H * 16 * C * 576 * 4 + (size_t)B * H * (C / 16 + 9) * 18 * 1024;   // partial maps + P fragments
+      const size_t need = msa_row_split_scratch_bytes(B, R, C, H, (int)(job_batch(B) * H));
+      if (need) {
         if (need <= ((size_t)1 << 31) && !(rc = scores.ensure(need, stream))) part = scores.as<float>();
-        else if (order_items) return fail(PG_ERR_INVALID, "too many MSAs in one call for the row-split attention scratch: use smaller template batches");
+        else return fail(PG_ERR_INVALID, "too many MSAs in one call for the row-split attention scratch: use smaller batches");
       }
-      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0, (int)(job_batch(B) * H)); }))) return rc;
     } else {
       // alignments wider than the MFMA row-attention kernel's register budget: fp32 scores through a scratch buffer
       if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * msa_row_scores_ld(C) * 4, stream))) return rc;

@@ -53,9 +53,12 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
                               int pad_idx = -1);
 // MSA tied row attention: one C x C map per (msa, head) from scores summed over the R rows
 // `partial` (optional fp32 scratch of partial_bytes) enables the split-R mode used when B*H is small
+// order_bh (0 = B * H): the (msa, head) count the split-R decision is taken on (job-level, so that shards agree);
+// msa_row_split_scratch_bytes: the fp32 scratch `partial` must offer for the split form (0 = this shape does not split)
+size_t msa_row_split_scratch_bytes(int B, int R, int C, int H, int order_bh);
 int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
                                   int ld_ctx, int k_off, int v_off, float scale, float* partial = nullptr,
-                                  size_t partial_bytes = 0);
+                                  size_t partial_bytes = 0, int order_bh = 0);
 
 int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,

@@ -253,22 +253,45 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
   }
 }
 
-int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
-                                  int ld_ctx, int k_off, int v_off, float scale, float* partial, size_t partial_bytes) {
-  if (B == 0 || R == 0) return 0;
-  if (C <= 0) return fail(1, "row attention: empty alignment");
-  const int n_bh = B * H, chunks = (C + 15) / 16;
-  // workgroup width: 4 waves up to 64 columns, beyond that the widest the register
-  // budget of the score fragments allows (9 waves up to 288 keys, 8 beyond)
-  const int nw = C <= 64 ? 4 : (C <= 288 ? 9 : 8);    // must match the NW of the instantiation that serves this C
-  const int n_qblk = (chunks + nw - 1) / nw;
-  // split the row loop over workgroups when the (msa, head, query-chunk) grid alone cannot fill the chip
-  int n_rc = 1;
-  if (partial && n_bh * n_qblk < 384 && R >= 8) {
-    n_rc = 512 / (n_bh * n_qblk);                     // two whole rounds of one workgroup per CU (measured best: 512 vs 768)
+// split-R geometry, shared by the launcher and by the engine's scratch sizing
+static void row_split_geometry(int n_bh, int obh, int R, int C, int& nw, int& n_qblk, int& n_rc, int& kb) {
+  const int chunks = (C + 15) / 16;
+  nw = C <= 64 ? 4 : (C <= 288 ? 9 : 8);
+  n_qblk = (chunks + nw - 1) / nw;
+  n_rc = 1;
+  if (obh * ((C + 63) / 64) < 384 && obh * n_qblk < 384 && R >= 8) {      // few (msa, head, 64-query) units: the chip would idle
+    n_rc = 512 / (obh * n_qblk);                      // two whole rounds of one workgroup per CU (measured best: 512 vs 768)
     if (n_rc > R / 4) n_rc = R / 4;
     if (n_rc < 1) n_rc = 1;
   }
+  static const int kbs[] = {2, 4, 8, 12, 18, 24, 30, 36};
+  kb = 36;
+  for (int k : kbs)
+    if (C <= k * 16) { kb = k; break; }
+  (void)n_bh;
+}
+// bytes of fp32 scratch the split-R form needs for B alignments (0: the shape does not split)
+size_t msa_row_split_scratch_bytes(int B, int R, int C, int H, int order_bh) {
+  if (C > 576) return 0;
+  int nw, n_qblk, n_rc, kb;
+  row_split_geometry(B * H, order_bh > 0 ? order_bh : B * H, R, C, nw, n_qblk, n_rc, kb);
+  if (n_rc <= 1) return 0;
+  return (size_t)B * H * n_rc * C * (kb * 16) * 4 + (size_t)B * H * n_qblk * nw * (kb / 2) * 1024;
+}
+
+int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int R, int C, int H, int ld_qkv,
+                                  int ld_ctx, int k_off, int v_off, float scale, float* partial, size_t partial_bytes,
+                                  int order_bh) {
+  if (B == 0 || R == 0) return 0;
+  if (C <= 0) return fail(1, "row attention: empty alignment");
+  const int n_bh = B * H;
+  // workgroup width: 4 waves up to 64 columns, beyond that the widest the register budget of the score fragments allows
+  // (9 waves up to 288 keys, 8 beyond).  The row loop is split over workgroups when the (msa, head, query-chunk) grid alone
+  // cannot fill the chip; the number of row chunks fixes the order of the sum over alignment rows, so it is derived from
+  // order_bh -- the (msa, head) count of the JOB, or of ONE template in a batched generate_single -- not from this call's share
+  int nw, n_qblk, n_rc, kb_;
+  row_split_geometry(n_bh, order_bh > 0 ? order_bh : n_bh, R, C, nw, n_qblk, n_rc, kb_);
+  if (!partial) n_rc = 1;
 #define PG_ROWATT_K(KB, NWV, MODE, GRID, BLOCK)                                                                          \
   hipLaunchKernelGGL((msa_row_attention_kernel<KB, NWV, MODE>), GRID, BLOCK, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx,     \
                      k_off, v_off, scale, n_qblk, n_bh, n_rc, partial)

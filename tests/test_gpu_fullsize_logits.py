@@ -18,7 +18,26 @@ from protein_gibbs_sampler_amd import models, weights
 pytestmark = pytest.mark.gpu
 
 STRICT_TOL = 1e-3      # north_star
-BF16_REL = 0.06        # bf16 operands through 33 layers: max error held to 6 % of the logit spread (measured 4-5 %, printed)
+# bf16 mode (does NOT meet 1e-3), at logit std ~ 10.  The MAX error and the argmax agreement are noisy
+# statistics of a 33-layer bf16 pipeline: two builds whose LayerNorm differs only in the order of two fused multiply-adds
+# measured 0.302 / 0.9987 and 0.347 / 0.9948 on the same inputs (MSA-1b 0.242 / 0.9936 and 0.212 / 0.9932; config 1 0.330 and
+# 0.269), so they are held to the worse figure plus ~30 %; the MEAN error is stable (ESM-1b 0.0590 / 0.0592, MSA-1b 0.0356 /
+# 0.0356) and held to +25 %.  (profiles/r03_gpu_parity_figures.txt)
+BF16_MAX_ESM, BF16_AGREE_ESM, BF16_MEAN_ESM = 0.45, 0.990, 0.074
+BF16_MAX_MSA, BF16_AGREE_MSA, BF16_MEAN_MSA = 0.32, 0.990, 0.045
+BF16_MAX_CFG1 = 0.43
+
+
+def _kl_valid(got, want, valid):
+    """KL(softmax(got[valid]) || softmax(want[valid])) per row: what a bf16 logit error does to the distribution the sampler
+    draws from (generate_step restricts to the valid residues before the softmax, esm_sampler.py:28-41)."""
+    a = got[..., valid].astype(np.float64)
+    b = want[..., valid].astype(np.float64)
+    la = a - a.max(-1, keepdims=True)
+    la = la - np.log(np.exp(la).sum(-1, keepdims=True))
+    lb = b - b.max(-1, keepdims=True)
+    lb = lb - np.log(np.exp(lb).sum(-1, keepdims=True))
+    return (np.exp(la) * (la - lb)).sum(-1)
 
 
 @pytest.fixture(scope="module")
@@ -46,11 +65,18 @@ def test_esm1b_full_size_all_logits(esm_case, precision):
     agree = (got.argmax(-1) == want.argmax(-1)).mean()
     print("\n[ESM-1b 33 x 1280, %s] max|engine - oracle| = %.3e  mean = %.3e  (logit std %.2f, max|logit| %.1f, argmax agreement %.4f)"
           % (precision, err.max(), err.mean(), want.std(), np.abs(want).max(), agree))
+    # the distribution the sampler draws from, at the masked rows (the rows a Gibbs iteration samples)
+    masked = tok == 32
+    kl = _kl_valid(got[masked], want[masked], list(range(4, 24)))
+    print("[ESM-1b 33 x 1280, %s] KL(engine || oracle) over the 20 residues at the %d masked rows: mean %.3e max %.3e"
+          % (precision, masked.sum(), kl.mean(), kl.max()))
     if precision == "fp32":
         assert err.max() < STRICT_TOL
         assert agree > 0.999            # flips only between near-tied logits (gap < 2e-3)
+        assert kl.max() < 1e-6
     else:
-        assert err.max() < BF16_REL * want.std() and agree > 0.97
+        assert err.max() < BF16_MAX_ESM and agree >= BF16_AGREE_ESM and err.mean() < BF16_MEAN_ESM
+        assert kl.mean() < 6e-4 and kl.max() < 1.5e-2          # measured 2.9e-4 / 4.7e-3 (ESM-1b), 2.4e-4 / 3.6e-3 (MSA-1b)
 
 
 @pytest.fixture(scope="module")
@@ -80,11 +106,17 @@ def test_msa1b_full_size_all_logits(msa_case, precision):
     agree = (got.argmax(-1) == want.argmax(-1)).mean()
     print("\n[MSA-1b 12 x 768, %s] max|engine - oracle| = %.3e  mean = %.3e  (logit std %.2f, max|logit| %.1f, argmax agreement %.4f)"
           % (precision, err.max(), err.mean(), want.std(), np.abs(want).max(), agree))
+    masked = tok == 32
+    kl = _kl_valid(got[masked], want[masked], list(range(4, 24)) + [30])
+    print("[MSA-1b 12 x 768, %s] KL(engine || oracle) over the 21 symbols at the %d masked positions: mean %.3e max %.3e"
+          % (precision, masked.sum(), kl.mean(), kl.max()))
     if precision == "fp32":
         assert err.max() < STRICT_TOL
         assert agree > 0.999            # flips only between near-tied logits (gap < 2e-3)
+        assert kl.max() < 1e-6
     else:
-        assert err.max() < BF16_REL * want.std() and agree > 0.97
+        assert err.max() < BF16_MAX_MSA and agree >= BF16_AGREE_MSA and err.mean() < BF16_MEAN_MSA
+        assert kl.mean() < 6e-4 and kl.max() < 1.5e-2          # measured 2.9e-4 / 4.7e-3 (ESM-1b), 2.4e-4 / 3.6e-3 (MSA-1b)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -124,7 +156,7 @@ def test_config1_full_size_single_chain(esm_case, precision):
         assert (want == run["sampled_tokens"][it].reshape(-1)).all()
         tok[0, table[it, 0]] = want
     print("\n[config 1, ESM-1b 33 x 1280, %s] max|engine - oracle| over 20 iterations = %.3e" % (precision, worst))
-    assert worst < (STRICT_TOL if precision == "fp32" else BF16_REL * 10.0)
+    assert worst < (STRICT_TOL if precision == "fp32" else BF16_MAX_CFG1)
     assert (tok == run["tokens"]).all() and out == s.untokenize_batch(torch_from(tok), True, True)
     # the unrecorded run replays the loop from one captured hipGraph: same strings
     s.record = False
