@@ -571,6 +571,11 @@ static BigGeom big_geometry(int M, int N, int K) {
   }
   return g;
 }
+void gemm_big_geometry(int M, int N, int K, int* m_main_panels, int* tail_rows) {
+  const BigGeom g = big_geometry(M, N, K);
+  *m_main_panels = g.m_main;
+  *tail_rows = g.tail_rows;
+}
 // EPI_F32_RESID_LN needs every row panel's column tiles on one XCD (gemm_epilogue.h): XCD x owns the contiguous tile range
 // [x q + min(x, r), ...) of the grouped order, a group being gm m-panels x all n-tiles -- so every range must begin on a group
 // boundary; tail row blocks must divide by 8.

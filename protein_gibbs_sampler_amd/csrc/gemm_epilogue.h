@@ -117,7 +117,10 @@ __device__ __forceinline__ void ln_when_panel_complete(const EpiAux& aux, int sl
 // instruction and k order as every other tile kernel: a row's result does not depend on which tile shape computed it.
 //   stage = 64 X rows + 64 W rows of 128 B = 16 pieces of 1 KiB (8 rows each); wave w stages piece w (and w + 8 with 8 waves)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NW, int EPI>
+// SPLIT3 (strict precision mode, gemm_w16.hip): operands in the split layout, K = logical depth; a K-step is one group of 32
+// columns -- 128 B per row: xl | xh, wh | wl -- at a source stride of 192 B, and three products per step in the fused kernel's
+// order (wh.xl, wl.xh, wh.xh).
+template <int NW, int EPI, bool SPLIT3 = false>
 __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                  const float* __restrict__ bias, void* __restrict__ out, int K, int ldx, int ldw,
                                                  int ldo, int m0, int n0, char* smem, int ln_slot, const EpiAux& aux) {
@@ -126,20 +129,22 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
   typedef EpiTraits<EPI> T;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nk = K / 64;
+  const int nk = SPLIT3 ? K / 32 : K / 64;
+  const int kbytes = (SPLIT3 ? 3 * K : K) * 2;           // bytes of an operand row
+  constexpr int KSTEP_BYTES = SPLIT3 ? 192 : 128;
 
   // piece p (0-7: X rows 8p .., 8-15: W rows 8(p-8) ..): wave w stages piece w, and with 8 waves also piece w + 8 -- so piece A is
   // an X piece for w < 8 and piece B (8 waves only) always a W piece.  (No arrays of buffer resources: the type is opaque.)
   const bool a_is_w = wave >= 8;
   const int ld_a = a_is_w ? ldw : ldx;
   const bf16_t* src_a = a_is_w ? W + (size_t)(n0 + (wave - 8) * 8) * ldw : X + (size_t)(m0 + wave * 8) * ldx;
-  const rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src_a, 0, (7 * ld_a + K) * 2, 0x00020000);
+  const rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src_a, 0, 7 * ld_a * 2 + kbytes, 0x00020000);
   const int voff_a = ((lane >> 3) * ld_a + ((lane & 7) ^ (lane >> 3)) * 8) * 2;
-  const rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)(n0 + (wave & 7) * 8) * ldw), 0, (7 * ldw + K) * 2, 0x00020000);
+  const rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (size_t)(n0 + (wave & 7) * 8) * ldw), 0, 7 * ldw * 2 + kbytes, 0x00020000);
   const int voff_b = ((lane >> 3) * ldw + ((lane & 7) ^ (lane >> 3)) * 8) * 2;
   auto dma = [&](int t) {
     char* dst = smem + (t & (STAGES - 1)) * STAGE_BYTES;
-    const int soff = t < nk ? t * 128 : 0x7f000000;          // past the end of K: out of range, no memory traffic
+    const int soff = t < nk ? t * KSTEP_BYTES : 0x7f000000;  // past the end of K: out of range, no memory traffic
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, PG_LDS_PTR(dst + wave * 1024), 16, voff_a, soff, 0, 0);
     if (PPW == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, PG_LDS_PTR(dst + (wave + 8) * 1024), 16, voff_b, soff, 0, 0);
   };
@@ -162,6 +167,17 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
     __builtin_amdgcn_sched_barrier(0);
     dma(t + STAGES - 1);                   // ... which the pieces of step t+7 now overwrite
     const char* sb = smem + (t & (STAGES - 1)) * STAGE_BYTES;
+    if (SPLIT3) {
+      const bf16x8 wh = *(const bf16x8*)(sb + 8192 + ni * 2048 + fo0), wl = *(const bf16x8*)(sb + 8192 + ni * 2048 + fo1);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const bf16x8 xl = *(const bf16x8*)(sb + (mi0 + j) * 2048 + fo0), xh = *(const bf16x8*)(sb + (mi0 + j) * 2048 + fo1);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[j], 0, 0, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int fo = kk ? fo1 : fo0;
@@ -182,6 +198,27 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
   for (int j = 0; j < TM; ++j) {
     const int m_loc = (mi0 + j) * 16 + fr;
     float v0 = acc[j][0] + b4.x, v1 = acc[j][1] + b4.y, v2 = acc[j][2] + b4.z, v3 = acc[j][3] + b4.w;
+    if (EPI == EPI_SPLIT3_GELU) {
+      // strict fc1: GELU, the value split into its bf16 (hi, lo) pair, written as fc2's operand row [lo | hi | hi] per 32 columns
+      // (ldo = 3 N) -- the arithmetic of tile256_epilogue's EPI_SPLIT3_GELU branch
+#if PG_STRICT_GELU_POLY
+      const pg_f32x2 ga = gelu_poly2(v0, v1), gb = gelu_poly2(v2, v3);
+      const float g0 = ga[0], g1 = ga[1], g2 = gb[0], g3 = gb[1];
+#else
+      const float g0 = gelu_erf(v0), g1 = gelu_erf(v1), g2 = gelu_erf(v2), g3 = gelu_erf(v3);
+#endif
+      uint2 hi, lo;
+      hi.x = pack_bf16x2(g0, g1);
+      hi.y = pack_bf16x2(g2, g3);
+      lo.x = pack_bf16x2(g0 - __uint_as_float(hi.x << 16), g1 - __uint_as_float(hi.x & 0xffff0000u));
+      lo.y = pack_bf16x2(g2 - __uint_as_float(hi.y << 16), g3 - __uint_as_float(hi.y & 0xffff0000u));
+      const int n = n0 + n_loc;
+      bf16_t* o3 = (bf16_t*)out + (size_t)(m0 + m_loc) * ldo + (n >> 5) * 96 + (n & 31);
+      *(uint2*)o3 = lo;
+      *(uint2*)(o3 + 32) = hi;
+      *(uint2*)(o3 + 64) = hi;
+      continue;
+    }
     const size_t o = (size_t)(m0 + m_loc) * ldo + n0 + n_loc;
     if (T::bf16out) {
       uint2 p;

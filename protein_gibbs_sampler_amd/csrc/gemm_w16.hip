@@ -171,12 +171,21 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
 template <int EPI, int GM>
 __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                                  const float* __restrict__ bias, void* __restrict__ out, int K,
-                                                                 int ldx, int ldw, int ldo, int tiles_n, int n_tiles) {
+                                                                 int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
+                                                                 int tail_m0) {
   __shared__ __attribute__((aligned(16))) char smem[2 * W16_KSLOT];
+  // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
+  if ((int)blockIdx.x < n_tail) {
+    const int out_cols = EPI == EPI_SPLIT3_GELU ? ldo / 3 : ldo;
+    const int tn64 = tiles_n * 4, bt = blockIdx.x;
+    (void)out_cols;
+    gemm_tail_tile64<16, EPI, true>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, 0, EpiAux{});
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave & 3, wn = wave >> 2;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x - n_tail;
   {
     const int xcd = bid & 7, q = n_tiles >> 3, r = n_tiles & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -272,14 +281,18 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
 // epi: EPI_F32, EPI_F32_RESID or EPI_SPLIT3_GELU.
 int launch_gemm_split3_w16(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K,
                            int ldo, int epi) {
-  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
-  if (M % 256 || N % 256 || K % 32 || K < 32 || n_tiles < 1) return fail(1, "gemm_split3_w16: shape");
+  if (M % 256 || N % 256 || K % 32 || K < 32 || M < 256) return fail(1, "gemm_split3_w16: shape");
+  // whole rounds of 256 x 256 tiles + 64 x 64 tail tiles for the rows of a mostly empty last round, as launch_gemm_big
+  int m_main = M / 256, tail_rows = 0;
+  gemm_big_geometry(M, N, 3 * K, &m_main, &tail_rows);
+  const int tiles_m = m_main, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+  const int n_tail = (tail_rows / 64) * (N / 64), tail_m0 = m_main * 256;
   const int gm = K >= 4096 ? 2 : 4;
-  dim3 grid(n_tiles), block(1024);
+  dim3 grid(n_tiles + n_tail), block(1024);
 #define PG_S3_CASE(E)                                                                                                          \
   case E:                                                                                                                      \
-    if (gm == 2) hipLaunchKernelGGL((gemm_split3_w16_kernel<E, 2>), grid, block, 0, s, X3, W3, bias, out, K, 3 * K, 3 * K, ldo, tiles_n, n_tiles); \
-    else hipLaunchKernelGGL((gemm_split3_w16_kernel<E, 4>), grid, block, 0, s, X3, W3, bias, out, K, 3 * K, 3 * K, ldo, tiles_n, n_tiles);     \
+    if (gm == 2) hipLaunchKernelGGL((gemm_split3_w16_kernel<E, 2>), grid, block, 0, s, X3, W3, bias, out, K, 3 * K, 3 * K, ldo, tiles_n, n_tiles, n_tail, tail_m0); \
+    else hipLaunchKernelGGL((gemm_split3_w16_kernel<E, 4>), grid, block, 0, s, X3, W3, bias, out, K, 3 * K, 3 * K, ldo, tiles_n, n_tiles, n_tail, tail_m0);     \
     break;
   switch (epi) {
     PG_S3_CASE(EPI_F32)

@@ -31,6 +31,8 @@ struct EpiAux;       // gemm_epilogue.h: operands of the LayerNorm-folding epilo
 // the big-batch GEMM: whole rounds of 256 x 256 tiles + 64 x 64 tail tiles in one grid (gemm_bf16.hip); M, N multiples of 256
 int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                     int ldw, int ldo, int epi, const EpiAux* aux = nullptr);
+// its split of the rows: m-panels of 256 x 256 tiles (whole rounds of one tile per CU) + rows of 64 x 64 tail tiles
+void gemm_big_geometry(int M, int N, int K, int* m_main_panels, int* tail_rows);
 // may a launch_gemm_big(..., EPI_F32_RESID_LN) of this shape normalise inside the GEMM? (every row panel's tiles on one XCD)
 bool gemm_big_can_fuse_ln(int M, int N, int K);
 // the 16-wave 256x256 tile kernel (gemm_w16.hip): M (may be 0 with tail_rows > 0), N multiples of 256, K a multiple of 64;
