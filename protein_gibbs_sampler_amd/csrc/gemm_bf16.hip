@@ -635,7 +635,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int k = 0;
-  constexpr int U = MT <= 4 ? 4 : (MT <= 8 ? 2 : 1);     // MFMA k-steps per trip (all loads issued first; <= 64 fragment VGPRs)
+  // MFMA k-steps per trip (all loads issued first).  5 for up to two m-tiles: a wave's share of K = 1280 with 8 waves is 160 =
+  // 5 x 32, ONE batch of loads instead of 4 + 1 -- the kernel is a chain of memory round trips (same k order, same bits)
+  constexpr int U = MT <= 2 ? 5 : (MT <= 4 ? 4 : (MT <= 8 ? 2 : 1));
   for (; k + 32 * U <= kq; k += 32 * U) {
     bf16x8 wf[U], xf[U][MT];
 #pragma unroll
