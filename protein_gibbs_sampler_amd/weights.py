@@ -143,7 +143,10 @@ def normalise_state_dict(sd, cfg, fair_esm_layout=True):
         raise KeyError("checkpoint is missing %d tensors, e.g. %s" % (len(missing), missing[:3]))
     if fair_esm_layout and cfg.get("token_dropout"):
         # fair-esm zeroes the <mask> embedding row when it loads an ESM-1b checkpoint ("For token drop", [recalled]); the
-        # forward never reads that row as an input (masked positions are zeroed), but the tied decoder does: logit[<mask>]
+        # forward never reads that row as an input (masked positions are zeroed), but the tied decoder does: after loading,
+        # logit[<mask>] = lm_head.bias[<mask>] only.  The samplers never draw <mask> (it is not in valid_aa_idx) and
+        # log_likelihood gathers the log-softmax at real residues, whose normaliser includes that bias-only term -- exactly
+        # what fair-esm computes after the same zeroing.  [recalled]: not checkable offline; a real checkpoint file decides.
         out["embed_tokens.weight"] = out["embed_tokens.weight"].copy()
         out["embed_tokens.weight"][cfg["mask_idx"]] = 0.0
     return out
