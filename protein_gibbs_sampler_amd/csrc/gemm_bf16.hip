@@ -245,7 +245,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep, !(EPI == EPI_F32_RESID_LN && (aux.flags & 1)));
+        buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep, !(aux.flags & 1));
       }
       __syncthreads();
       stage(1);
@@ -254,7 +254,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep, !(EPI == EPI_F32_RESID_LN && (aux.flags & 1)));
+        buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep, !(aux.flags & 1));
       }
       return;
     }
@@ -500,7 +500,9 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
                      int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0, const EpiAux* aux = nullptr) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   const int n_tail = (tail_rows / 64) * (N / 64), tail_m0 = M;
-  const EpiAux ax = aux ? *aux : EpiAux{};
+  EpiAux ax = aux ? *aux : EpiAux{};
+  static const int plain_stores = [] { const char* e = getenv("PGIBBS_RESID_PLAIN_STORES"); return e ? atoi(e) : 0; }();
+  if (plain_stores) ax.flags |= 1;
   dim3 grid(n_tiles + n_tail), block(512);
 #define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax
   if (abl) {   // ablations: EPI_BF16 only

@@ -24,7 +24,7 @@ STRICT_TOL = 1e-3      # north_star
 # 0.269), so they are held to the worse figure plus ~30 %; the MEAN error is stable (ESM-1b 0.0590 / 0.0592, MSA-1b 0.0356 /
 # 0.0356) and held to +25 %.  (profiles/r03_gpu_parity_figures.txt)
 BF16_MAX_ESM, BF16_AGREE_ESM, BF16_MEAN_ESM = 0.45, 0.990, 0.074
-BF16_MAX_MSA, BF16_AGREE_MSA, BF16_MEAN_MSA = 0.32, 0.990, 0.045
+BF16_MAX_MSA, BF16_AGREE_MSA, BF16_MEAN_MSA = 0.32, 0.985, 0.045
 BF16_MAX_CFG1 = 0.43
 
 
