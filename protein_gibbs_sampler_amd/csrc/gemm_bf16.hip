@@ -328,10 +328,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
-  if (ABL == 0 && (int)blockIdx.x < n_tail) {
+  // n_tail > 0: they are the FIRST workgroups of the grid; n_tail < 0: the LAST |n_tail| (PGIBBS_GEMM_TAIL_LAST)
+  const int nt_abs = n_tail < 0 ? -n_tail : n_tail;
+  if (ABL == 0 && nt_abs && (n_tail > 0 ? (int)blockIdx.x < nt_abs : (int)blockIdx.x >= n_tiles)) {
     // workgroup b runs on XCD b % 8: all column tiles of a 64-row block go to one XCD (its L2 is where a fused LayerNorm meets
     // the rows, gemm_epilogue.h) whenever the row blocks divide by 8 (tail rows are multiples of 256: at least by 4)
-    const int tn64 = tiles_n * 4, bt = blockIdx.x, n_rb = n_tail / tn64;
+    const int tn64 = tiles_n * 4, bt = n_tail > 0 ? blockIdx.x : blockIdx.x - n_tiles, n_rb = nt_abs / tn64;
     int rb, tn;
     if ((n_rb & 7) == 0) { const int j = bt >> 3; rb = (j / tn64) * 8 + (bt & 7); tn = j % tn64; }
     else { rb = bt / tn64; tn = bt % tn64; }
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   const int grp = wave >> 2;                      // 0: leads, 1: lags by one barrier
   const int wm = grp, wn = wave & 3;              // wave tile: rows wm*128.. of X, rows wn*64.. of W
 
-  int bid = blockIdx.x - n_tail;
+  int bid = n_tail > 0 ? blockIdx.x - n_tail : blockIdx.x;
   if (ABL == 18 && (bid & 7) != 0) return;        // timing experiment: only the workgroups of XCD 0 run (1/8 of the tiles)
   if (ABL == 19 && (bid & 7) > 1) return;         // ... XCDs 0 and 1
   {
@@ -499,11 +501,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0, const EpiAux* aux = nullptr) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
-  const int n_tail = (tail_rows / 64) * (N / 64), tail_m0 = M;
+  static const int tail_last = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_LAST"); return e ? atoi(e) : 0; }();
+  const int n_tail_abs = (tail_rows / 64) * (N / 64), tail_m0 = M;
+  const int n_tail = (tail_last && epi != EPI_F32_RESID_LN) ? -n_tail_abs : n_tail_abs;
   EpiAux ax = aux ? *aux : EpiAux{};
   static const int plain_stores = [] { const char* e = getenv("PGIBBS_RESID_PLAIN_STORES"); return e ? atoi(e) : 0; }();
   if (plain_stores) ax.flags |= 1;
-  dim3 grid(n_tiles + n_tail), block(512);
+  dim3 grid(n_tiles + n_tail_abs), block(512);
 #define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax
   if (abl) {   // ablations: EPI_BF16 only
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, PG_PP_ARGS);

@@ -53,8 +53,9 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
   __shared__ __attribute__((aligned(16))) char smem[2 * W16_KSLOT];
 
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
-  if (ABL == 0 && (int)blockIdx.x < n_tail) {
-    const int tn64 = tiles_n * 4, bt = blockIdx.x;
+  const int nt_abs = n_tail < 0 ? -n_tail : n_tail;       // n_tail < 0: the tail workgroups are the LAST of the grid
+  if (ABL == 0 && nt_abs && (n_tail > 0 ? (int)blockIdx.x < nt_abs : (int)blockIdx.x >= n_tiles)) {
+    const int tn64 = tiles_n * 4, bt = n_tail > 0 ? blockIdx.x : blockIdx.x - n_tiles;
     gemm_tail_tile64<16, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, 0, aux);
     return;
   }
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave & 3, wn = wave >> 2;           // wave tile: X rows wm*64 .., W rows wn*64 ..
 
-  int bid = blockIdx.x - n_tail;
+  int bid = n_tail > 0 ? blockIdx.x - n_tail : blockIdx.x;
   {
     const int xcd = bid & 7, q = n_tiles >> 3, r = n_tiles & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -319,9 +320,11 @@ static int launch_w16_abl(hipStream_t s, const bf16_t* X, const bf16_t* W, const
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                     int ldw, int ldo, int epi, int abl, int tail_rows, const EpiAux* aux) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
-  const int n_tail = (tail_rows / 64) * (N / 64), tail_m0 = M;
+  static const int tail_last = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_LAST"); return e ? atoi(e) : 0; }();
+  const int n_tail_abs = (tail_rows / 64) * (N / 64), tail_m0 = M;
+  const int n_tail = tail_last ? -n_tail_abs : n_tail_abs;
   const EpiAux ax = aux ? *aux : EpiAux{};
-  if (M % 256 || N % 256 || K % 64 || K < 64 || tail_rows % 64 || n_tiles + n_tail < 1) return fail(1, "gemm_w16: shape");
+  if (M % 256 || N % 256 || K % 64 || K < 64 || tail_rows % 64 || n_tiles + n_tail_abs < 1) return fail(1, "gemm_w16: shape");
   switch (abl) {
     case 0: break;
     case 1: return launch_w16_abl<1>(s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles);
@@ -333,7 +336,7 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
   }
   static const int gm_env = [] { const char* e = getenv("PGIBBS_GEMM_GM"); return e ? atoi(e) : 0; }();
   const int gm = gm_env ? gm_env : (K >= 4096 ? 2 : 4);
-  dim3 grid(n_tiles + n_tail), block(1024);
+  dim3 grid(n_tiles + n_tail_abs), block(1024);
 #define PG_W16_CASE(E)                                                                                                     \
   case E:                                                                                                                  \
     if (gm == 2) hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 2, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax); \
