@@ -321,17 +321,25 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   // <= 256 rows: 64-row tiles, <= 48 rows the weight-streaming GEMM (buffers stay 256-padded) -- the latter not for a tiny shard
   // of a big job (sel_gemm_rows)
   const int Mi = sel_gemm_rows(M, Mp);
+  // single chains (<= 32 token rows): LayerNorm is folded into the operand load of the weight-streaming QKV / fc1 GEMMs
+  // (gemm_ln_skinny_kernel) -- two launches per layer less in the launch-bound regime
+  const bool ln_in_gemm = gemm_ln_skinny_ok(Mi, 3 * d, d) && gemm_ln_skinny_ok(Mi, f, d);
 
   rc = timed(PC_EMBED, [&] {
     return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
                            cfg.mask_idx, cfg.token_dropout, 0, eps);
   });
   if (rc) return rc;
-  if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, esm_layers[0].ln1.g, esm_layers[0].ln1.b, Hh, M, d, eps); }))) return rc;
+  if (!ln_in_gemm)
+    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, esm_layers[0].ln1.g, esm_layers[0].ln1.b, Hh, M, d, eps); }))) return rc;
   for (int l = 0; l < cfg.n_layers; ++l) {
     const EsmLayer& L = esm_layers[l];
     // Hh holds LN1(x): written by the previous layer's fc2 launch (or the LayerNorm kernel) -- see resid_gemm_ln
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if (ln_in_gemm) {
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_ln_skinny(stream, X, d, L.ln1.g, L.ln1.b, eps, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    } else {
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    }
     if ((rc = timed(PC_ATTN, [&] { return launch_attention_bf16(stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: only the selected rows are ever read again -> gather them and finish the layer on n_sel rows
@@ -347,10 +355,20 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       });
       if (rc) return rc;
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.out.w, L.out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln2.g, L.ln2.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+      if (ln_in_gemm && gemm_ln_skinny_ok(Ni, f, d)) {
+        if ((rc = timed(PC_GEMM, [&] { return launch_gemm_ln_skinny(stream, XS, d, L.ln2.g, L.ln2.b, eps, L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, f, EPI_BF16_GELU); }))) return rc;
+      } else {
+        if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln2.g, L.ln2.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
+        if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+      }
       if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
+    }
+    if (ln_in_gemm) {
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_ln_skinny(stream, X, d, L.ln2.g, L.ln2.b, eps, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, f, EPI_BF16_GELU); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      continue;
     }
     if ((rc = resid_gemm_ln(CTX, L.out, X, Mi, M, d, L.ln2, Hh))) return rc;                       // x += out_proj(ctx); h = LN2(x)
     if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;

@@ -711,6 +711,177 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same weight-streaming GEMM with the preceding LayerNorm folded into its operand load (single chains: BASELINE config 1).
+//   out = LayerNorm(x; gamma, beta) . W^T + bias,   x fp32 [M <= 32 rows][K = d_model]
+// In the launch-bound regime a LayerNorm is a whole kernel (>= 4 us on this part, whatever it computes) for 140 KB of data
+// that the next GEMM's workgroups read anyway: every workgroup here loads the fp32 residual rows itself -- wave w its K slice
+// of every row --, the eight waves combine the row sums through LDS (two-pass: mean, then the centred sum of squares, on the
+// values held in registers), and each wave normalises its slice on the way into the MFMA.  No extra memory traffic (the
+// bf16 operand rows were re-read by every workgroup before; now it is the fp32 rows, from L2), two kernels per layer less.
+// The statistics are summed in another order than ln_row.h's (few-chain regime: kernels are picked by the local shape).
+// ------------------------------------------------------------------------------------------------
+// NB = 16-feature blocks per workgroup: 1, or 2 when N / 16 workgroups would not be resident at once (the row data is 80 VGPRs:
+// one 8-wave workgroup per CU) -- fc1's 320 then run as 160 workgroups in one dispatch round instead of 256 + 64.
+template <int MT, int EPI, int NKS, int NB>
+__global__ __launch_bounds__(512) void gemm_ln_skinny_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           const bf16_t* __restrict__ W, const float* __restrict__ bias,
+                                                           void* __restrict__ out, int K, int ldw, int ldo) {
+  constexpr int NW = 8;
+  __shared__ float red[NW - 1][MT][NB][64][4];
+  __shared__ float stat[2][NW][MT][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 16 * NB;
+  const int kq = NKS * 32;                               // this wave's K range (K = 8 * kq)
+  const int k0 = wave * kq + fq * 8;
+  const bf16_t* wp = W + (size_t)(n0 + fr) * ldw + k0;
+  const float* xp = X + (size_t)fr * ldx + k0;
+  bf16x8 wf[NKS][NB];
+  float4 xa[NKS][MT][2];
+#pragma unroll
+  for (int u = 0; u < NKS; ++u) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) wf[u][nb] = *(const bf16x8*)(wp + (size_t)nb * 16 * ldw + u * 32);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      xa[u][t][0] = *(const float4*)(xp + (size_t)t * 16 * ldx + u * 32);
+      xa[u][t][1] = *(const float4*)(xp + (size_t)t * 16 * ldx + u * 32 + 4);
+    }
+  }
+  const float inv_k = 1.0f / (float)K;
+  float mean[MT], rstd[MT];
+  // pass 1: row means (row = t*16 + fr; the four fq lanes of a row, then the eight waves)
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NKS; ++u)
+      s += ((xa[u][t][0].x + xa[u][t][0].y) + (xa[u][t][0].z + xa[u][t][0].w)) + ((xa[u][t][1].x + xa[u][t][1].y) + (xa[u][t][1].z + xa[u][t][1].w));
+    s = rows4_sum(s);
+    if (fq == 0) stat[0][wave][t][fr] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) s += stat[0][w2][t][fr];
+    mean[t] = s * inv_k;
+  }
+  // pass 2: centred sums of squares
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NKS; ++u)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float4& v = xa[u][t][hh];
+        v.x -= mean[t]; v.y -= mean[t]; v.z -= mean[t]; v.w -= mean[t];
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    q = rows4_sum(q);
+    if (fq == 0) stat[1][wave][t][fr] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    float q = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) q += stat[1][w2][t][fr];
+    rstd[t] = 1.0f / sqrtf(q * inv_k + eps);
+  }
+  f32x4 acc[MT][NB];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NKS; ++u) {
+    const float4 g0 = *(const float4*)(gamma + k0 + u * 32), g1 = *(const float4*)(gamma + k0 + u * 32 + 4);
+    const float4 b0 = *(const float4*)(beta + k0 + u * 32), b1 = *(const float4*)(beta + k0 + u * 32 + 4);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const float4 a = xa[u][t][0], b = xa[u][t][1];
+      const float r = rstd[t];
+      uint4 pk;
+      pk.x = pack_bf16x2(a.x * r * g0.x + b0.x, a.y * r * g0.y + b0.y);
+      pk.y = pack_bf16x2(a.z * r * g0.z + b0.z, a.w * r * g0.w + b0.w);
+      pk.z = pack_bf16x2(b.x * r * g1.x + b1.x, b.y * r * g1.y + b1.y);
+      pk.w = pack_bf16x2(b.z * r * g1.z + b1.z, b.w * r * g1.w + b1.w);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][nb], __builtin_bit_cast(bf16x8, pk), acc[t][nb], 0, 0, 0);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) *(f32x4*)&red[wave - 1][t][nb][lane][0] = acc[t][nb];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const float4 b4 = *(const float4*)(bias + n0 + nb * 16 + fq * 4);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      f32x4 v = acc[t][nb];
+#pragma unroll
+      for (int w2 = 0; w2 < NW - 1; ++w2) {
+        const f32x4 o = *(const f32x4*)&red[w2][t][nb][lane][0];
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+      }
+      const float v0 = v[0] + b4.x, v1 = v[1] + b4.y, v2 = v[2] + b4.z, v3 = v[3] + b4.w;
+      uint2 p;
+      p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
+      p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
+      *(uint2*)((bf16_t*)out + (size_t)(t * 16 + fr) * ldo + n0 + nb * 16 + fq * 4) = p;
+    }
+  }
+}
+
+// may the LayerNorm-folding weight-streaming GEMM take this shape?  (M rows incl. padding; K = the normalised width)
+bool gemm_ln_skinny_ok(int M, int N, int K) {
+  static const int on = [] { const char* e = getenv("PGIBBS_LN_SKINNY"); return e ? atoi(e) : 1; }();
+  return on && (M == 16 || M == 32) && N % 16 == 0 && K % 256 == 0 && K / 256 >= 1 && K / 256 <= 5;
+}
+int launch_gemm_ln_skinny(hipStream_t s, const float* X, int ldx, const float* gamma, const float* beta, float eps, const bf16_t* W,
+                          const float* bias, void* out, int M, int N, int K, int ldw, int ldo, int epi) {
+  if (!gemm_ln_skinny_ok(M, N, K) || (epi != EPI_BF16 && epi != EPI_BF16_GELU)) return fail(1, "gemm_ln_skinny: shape / epilogue");
+  const int nks = K / 256;
+  static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+  static const int nb_env = [] { const char* e = getenv("PGIBBS_LN_SKINNY_NB"); return e ? atoi(e) : 0; }();
+  const int nb = nb_env ? nb_env : ((N / 16 > n_cu && N % 32 == 0) ? 2 : 1);
+  if (nb == 2 && N % 32) return fail(1, "gemm_ln_skinny: N must be a multiple of 32 for two feature blocks per workgroup");
+  dim3 grid(N / (16 * nb)), block(512);
+#define PG_LNS(MTV, E, NK)                                                                                                       \
+  do {                                                                                                                           \
+    if (nb == 2) hipLaunchKernelGGL((gemm_ln_skinny_kernel<MTV, E, NK, 2>), grid, block, 0, s, X, ldx, gamma, beta, eps, W, bias, out, K, ldw, ldo); \
+    else hipLaunchKernelGGL((gemm_ln_skinny_kernel<MTV, E, NK, 1>), grid, block, 0, s, X, ldx, gamma, beta, eps, W, bias, out, K, ldw, ldo);     \
+  } while (0)
+#define PG_LNS_NK(MTV, E)                                                       \
+  switch (nks) {                                                                \
+    case 1: PG_LNS(MTV, E, 1); break;                                           \
+    case 2: PG_LNS(MTV, E, 2); break;                                           \
+    case 3: PG_LNS(MTV, E, 3); break;                                           \
+    case 4: PG_LNS(MTV, E, 4); break;                                           \
+    default: PG_LNS(MTV, E, 5); break;                                          \
+  }
+  if (M == 16) {
+    if (epi == EPI_BF16) { PG_LNS_NK(1, EPI_BF16) } else { PG_LNS_NK(1, EPI_BF16_GELU) }
+  } else {
+    if (epi == EPI_BF16) { PG_LNS_NK(2, EPI_BF16) } else { PG_LNS_NK(2, EPI_BF16_GELU) }
+  }
+#undef PG_LNS_NK
+#undef PG_LNS
+  PG_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int MT>
 static int launch_skinny_mt(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int N, int K, int ldx,
                             int ldw, int ldo, int epi, int splits = 1, long split_stride = 0) {

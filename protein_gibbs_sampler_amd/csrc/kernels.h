@@ -27,6 +27,11 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws = nullptr, size_t ws_bytes = 0);
 
+// weight-streaming GEMM with the preceding LayerNorm folded into its operand load (single chains; gemm_bf16.hip):
+// out bf16 = LayerNorm(x fp32 [M][K]; gamma, beta) . W^T + bias (+ GELU); M = 16 or 32 rows, K = 256 .. 1280 in steps of 256
+bool gemm_ln_skinny_ok(int M, int N, int K);
+int launch_gemm_ln_skinny(hipStream_t s, const float* X, int ldx, const float* gamma, const float* beta, float eps, const bf16_t* W,
+                          const float* bias, void* out, int M, int N, int K, int ldw, int ldo, int epi);
 struct EpiAux;       // gemm_epilogue.h: operands of the LayerNorm-folding epilogues
 // the big-batch GEMM: whole rounds of 256 x 256 tiles + 64 x 64 tail tiles in one grid (gemm_bf16.hip); M, N multiples of 256
 int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
