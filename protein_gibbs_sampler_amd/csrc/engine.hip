@@ -388,7 +388,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
 int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
                           float* ws, size_t ws_bytes) {
   const int d = W.N, K = W.K;
-  const bool big = fuse_ln && !prof_split_ln && M_rows % 256 == 0 && d % 256 == 0 && K >= 128 && K % 64 == 0 &&
+  const bool big = fuse_ln && M_rows % 256 == 0 && d % 256 == 0 && K >= 128 && K % 64 == 0 &&
                    (long)(M_rows / 256) * (d / 256) >= 128 &&      // the shapes launch_gemm_bf16 gives to the big-tile kernels
                    gemm_big_can_fuse_ln(M_rows, d, K);              // ... with every row panel's tiles on one XCD
   if (big) {
