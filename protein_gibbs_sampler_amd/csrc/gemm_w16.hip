@@ -3,7 +3,7 @@
 //
 // Same op, operand layout and k order as gemm_bf16.hip (every dense layer behind `self.model.model(batch)`,
 // /root/reference/src/pgen/esm_sampler.py:223).  Where the 8-wave ping-pong kernel hand-schedules two wave groups against
-// each other and the 4-wave kernel (gemm_w4.hip) software-pipelines inside one wave per SIMD, this one leaves the overlap to
+// each other and the 4-wave kernel (tools/probes/gemm_w4.hip) software-pipelines inside one wave per SIMD, this one leaves the overlap to
 // the hardware: four waves per SIMD at <= 128 VGPRs, a plain loop per wave
 //     wait for my DMA pieces of K-step t -> s_barrier -> issue the pieces of K-step t+1 -> 2 x (8 fragment reads, 16 MFMAs)
 // and the SIMD's scheduler runs one wave's MFMAs under the others' LDS reads, DMA issue and barrier waits.  The price is LDS
