@@ -306,6 +306,9 @@ HF_CASES = {
     # name: (cfg kwargs, weight seed, std, embed_std, ln_jitter, token rows)
     "tiny": (dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=64), 7, 0.08, 0.5, 0.1),
     "small": (dict(d_model=256, n_layers=4, n_heads=4, d_ffn=512, max_pos=300), 11, 0.05, 0.3, 0.1),
+    # the REAL ESM-1b sizes (33 layers, d = 1280, 20 heads, FFN 5120, 1024 positions; 650 M parameters) at a realistic logit
+    # scale: pins the full-size oracle -- and through it the engine -- to the independent implementation, not only small models
+    "full": (dict(d_model=1280, n_layers=33, n_heads=20, d_ffn=5120, max_pos=1024), 11, 0.025, 0.3, 0.1),
 }
 
 
@@ -313,6 +316,8 @@ def hf_tokens(name):
     rng = np.random.default_rng(99)
     if name == "tiny":
         B, L = 3, 25
+    elif name == "full":
+        B, L = 2, 256          # config 2's chain shape (T = 258)
     else:
         B, L = 2, 256
     tok = rng.integers(4, 24, size=(B, L + 2))
@@ -324,12 +329,14 @@ def hf_tokens(name):
     return tok
 
 
-def gen_hf():
+def gen_hf(only=None):
     import torch
     from transformers import EsmConfig as HC, EsmForMaskedLM
     from oracle.esm_forward import EsmConfig, synthetic_esm_weights, esm1b_forward
 
     for name, (ck, seed, std, estd, jit) in HF_CASES.items():
+        if only and name not in only:
+            continue
         cfg = EsmConfig(**ck)
         w = synthetic_esm_weights(cfg, seed=seed, std=std, embed_std=estd, ln_jitter=jit)
         hc = HC(vocab_size=33, hidden_size=cfg.d_model, num_hidden_layers=cfg.n_layers, num_attention_heads=cfg.n_heads,
@@ -413,6 +420,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["hf", "misc", "esm", "msa", "loglik"]
     if "hf" in which:
         gen_hf()
+    if "hf_full" in which:
+        gen_hf(only=("full",))
     if "misc" in which:
         gen_misc()
     if "esm" in which:

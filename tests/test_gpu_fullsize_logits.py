@@ -79,6 +79,34 @@ def test_esm1b_full_size_all_logits(esm_case, precision):
         assert kl.mean() < 6e-4 and kl.max() < 1.5e-2          # measured 2.9e-4 / 4.7e-3 (ESM-1b), 2.4e-4 / 3.6e-3 (MSA-1b)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_esm1b_full_size_against_huggingface(precision):
+    """The engine at the REAL ESM-1b sizes against logits recorded from HuggingFace's EsmForMaskedLM (tests/golden/esm_hf_full.npz,
+    generator tests/golden/make_golden.py hf_full: an implementation of the architecture that shares no code and no author with
+    oracle/esm_forward.py; the oracle itself agrees with it to 6.3e-5).  Strict mode: north_star's 1e-3 on all 2 x 258 x 33 logits."""
+    import json
+    from oracle.esm_forward import synthetic_esm_weights
+    z = np.load(__file__.rsplit("/", 1)[0] + "/golden/esm_hf_full.npz")
+    ck = json.loads(str(z["cfg"]))
+    ocfg = EsmConfig(**ck)
+    sd = synthetic_esm_weights(ocfg, seed=int(z["seed"]), std=float(z["std"]), embed_std=float(z["embed_std"]), ln_jitter=float(z["ln_jitter"]))
+    cfg = dict(weights.ESM1B_CONFIG)
+    assert (cfg["d_model"], cfg["n_layers"], cfg["d_ffn"], cfg["max_positions"]) == (ck["d_model"], ck["n_layers"], ck["d_ffn"], ck["max_pos"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = models.ESM1b(state_dict=sd, config=cfg, precision=precision).model.to("cuda:0")
+    got = m.forward_logits(z["tokens"])
+    err = np.abs(got - z["logits"])
+    agree = (got.argmax(-1) == z["logits"].argmax(-1)).mean()
+    print("\n[ESM-1b 33 x 1280 vs HuggingFace, %s] max|engine - HF| = %.3e  mean = %.3e  (logit std %.2f, argmax agreement %.4f)"
+          % (precision, err.max(), err.mean(), z["logits"].std(), agree))
+    if precision == "fp32":
+        assert err.max() < STRICT_TOL and agree > 0.999
+    else:
+        # measured 0.310 / mean 0.0604 / agreement 0.9845 (8 of 516 rows: these chains carry 10 % and 20 % masks -- more near-ties)
+        assert err.max() < BF16_MAX_ESM and agree >= 0.975 and err.mean() < BF16_MEAN_ESM
+
+
 @pytest.fixture(scope="module")
 def msa_case():
     cfg = dict(weights.MSA1B_CONFIG)

@@ -10,7 +10,9 @@ from oracle.esm_forward import EsmConfig, synthetic_esm_weights, esm1b_forward
 from _standin import GOLDEN
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+# "full" = the REAL ESM-1b sizes (33 layers, d = 1280, 650 M parameters; ~1 minute of numpy on the CPU container): the fixture
+# pins the FULL-SIZE oracle to the independent implementation at a realistic logit scale (std 10), not only the small models
+@pytest.mark.parametrize("name", ["tiny", "small", "full"])
 def test_esm1b_forward_matches_hf(name):
     z = np.load("%s/esm_hf_%s.npz" % (GOLDEN, name))
     cfg = EsmConfig(**json.loads(str(z["cfg"])))
