@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                       const float* __restrict__ pos, const float* __restrict__ msa_pos,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ x, int64_t n_tok, int T, int d, int pad_idx,
-                                                      int mask_idx, int token_dropout, int rows_per_msa, float eps) {
+                                                      int mask_idx, int token_dropout, int rows_per_msa, float eps,
+                                                      const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                      bf16_t* __restrict__ h2) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_tok) return;
@@ -75,7 +77,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
   float4* o = (float4*)(x + (size_t)row * d);
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
-    if (lane + 64 * i < nch4) o[lane + 64 * i] = is_pad ? make_float4(0.f, 0.f, 0.f, 0.f) : v[i];
+    if (lane + 64 * i < nch4) {
+      if (is_pad) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      o[lane + 64 * i] = v[i];
+    }
+  if (h2) {      // the first layer's LayerNorm on the row just written (same values, same code as layernorm_bf16_kernel: same bits)
+    ln_inplace(v, nch4, lane, d, eps, gamma2, beta2);
+    store_row_bf16(h2 + (size_t)row * d, v, nch4, lane);
+  }
 }
 
 // ---- LayerNorm: x fp32 [M][d] -> h bf16 [M][d] ------------------------------------------------
@@ -301,11 +310,12 @@ static inline unsigned rows_grid(int64_t rows) { return (unsigned)((rows + 3) / 
 
 int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,
-                    int mask_idx, int token_dropout, int rows_per_msa, float eps) {
+                    int mask_idx, int token_dropout, int rows_per_msa, float eps, const float* gamma2, const float* beta2,
+                    bf16_t* h2) {
   if (d % 4 || d > kMaxCh * 256) return fail(1, "embed: d must be a multiple of 4 and <= 2048");
   if (n_tok == 0) return 0;
   hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(n_tok)), dim3(256), 0, s, tokens, embed, pos, msa_pos, gamma, beta, x,
-                     n_tok, T, d, pad_idx, mask_idx, token_dropout, rows_per_msa, eps);
+                     n_tok, T, d, pad_idx, mask_idx, token_dropout, rows_per_msa, eps, gamma2, beta2, h2);
   PG_HIP(hipGetLastError());
   return 0;
 }

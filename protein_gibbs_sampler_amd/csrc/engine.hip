@@ -325,13 +325,13 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   // (gemm_ln_skinny_kernel) -- two launches per layer less in the launch-bound regime
   const bool ln_in_gemm = gemm_ln_skinny_ok(Mi, 3 * d, d) && gemm_ln_skinny_ok(Mi, f, d);
 
+  // embedding + emb_layer_norm_before, and in the same pass over the row the first layer's LayerNorm (its bf16 operand rows)
   rc = timed(PC_EMBED, [&] {
     return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
-                           cfg.mask_idx, cfg.token_dropout, 0, eps);
+                           cfg.mask_idx, cfg.token_dropout, 0, eps, ln_in_gemm ? nullptr : esm_layers[0].ln1.g,
+                           ln_in_gemm ? nullptr : esm_layers[0].ln1.b, ln_in_gemm ? nullptr : Hh);
   });
   if (rc) return rc;
-  if (!ln_in_gemm)
-    if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, esm_layers[0].ln1.g, esm_layers[0].ln1.b, Hh, M, d, eps); }))) return rc;
   for (int l = 0; l < cfg.n_layers; ++l) {
     const EsmLayer& L = esm_layers[l];
     // Hh holds LN1(x): written by the previous layer's fc2 launch (or the LayerNorm kernel) -- see resid_gemm_ln
@@ -577,14 +577,14 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     return PG_OK;
   }
 
+  // embedding + emb_layer_norm_before, and in the same pass over the row the first layer's row-attention LayerNorm
   rc = timed(PC_EMBED, [&] {
     return launch_embed_ln(stream, d_tok, embed, pos, msa_pos, ln_before.g, ln_before.b, X, M, C, d, cfg.pad_idx,
-                           cfg.mask_idx, 0, R, eps);
+                           cfg.mask_idx, 0, R, eps, msa_layers[0].ln_row.g, msa_layers[0].ln_row.b, Hh);
   });
   if (rc) return rc;
   const SeqLayout col = {C, R * C, 1, C};                   // column c of msa b: rows (b*R + r)*C + c
-  // Hh always holds the LayerNorm the next projection reads: written by the previous residual GEMM's launch (resid_gemm_ln)
-  if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, msa_layers[0].ln_row.g, msa_layers[0].ln_row.b, Hh, M, d, eps); }))) return rc;
+  // Hh always holds the LayerNorm the next projection reads: written by the embedding pass / the LayerNorm after a residual GEMM
   for (int l = 0; l < cfg.n_layers; ++l) {
     const MsaLayer& L = msa_layers[l];
     // tied row attention

@@ -69,7 +69,8 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
 
 int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,
-                    int mask_idx, int token_dropout, int rows_per_msa, float eps);
+                    int mask_idx, int token_dropout, int rows_per_msa, float eps,
+                    const float* gamma2 = nullptr, const float* beta2 = nullptr, bf16_t* h2 = nullptr);   // h2: also the first layer's LayerNorm of x
 int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
                           int d, float eps, bool split3 = false);   // split3: h rows are [lo | hi | hi], 3 d wide
 int launch_layernorm_f32(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int64_t M, int d,
