@@ -226,14 +226,6 @@ int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t*
  * (GELU, then the split operand rows fc2 reads; N a multiple of 256; out = hi + lo of those rows) */
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi);
-/* The residual GEMM that also normalises (csrc/gemm_epilogue.h, EPI_F32_RESID_LN), as the engine runs out-proj / fc2 at big
- * batches:  x = resid + a @ w^T + bias, and the workgroup that completes a row panel writes h = LayerNorm(x; gamma, beta) of its
- * rows.  resid_inout [M][N] is overwritten with x; h_fused = that launch's h (bf16 widened), h_kernel = the stand-alone
- * LayerNorm kernel on the same x: the two must be bit-identical.  `repeats` launches back to back (the arrival counters reset
- * themselves).  M, N multiples of 256, N <= 2048, K a multiple of 64.  Rows beyond the last full round of 256 x 256 tiles go
- * through 64 x 64 tail tiles, exactly as in the engine. */
-int pg_dbg_gemm_resid_ln(int device, const float* a, const float* w, const float* bias, float* resid_inout, const float* gamma,
-                         const float* beta, float* h_fused, float* h_kernel, int M, int N, int K, float eps, int repeats);
 /* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events; M a multiple of 16,
  * of 64 above 256); variant 1 =
  * lockstep kernel, 2 = ping-pong kernel; epi: 0 bf16 out, 1 bf16+gelu, 2 fp32 residual, 3 fp32, 4 fp32+gelu */

@@ -497,64 +497,6 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
   return PG_OK;
 }
 
-int pg_dbg_gemm_resid_ln(int device, const float* a, const float* w, const float* bias, float* resid_inout, const float* gamma,
-                         const float* beta, float* h_fused, float* h_kernel, int M, int N, int K, float eps, int repeats) {
-  if (!a || !w || !bias || !resid_inout || !gamma || !beta || !h_fused || !h_kernel) return fail(PG_ERR_INVALID, "pg_dbg_gemm_resid_ln: null argument");
-  if (M < 256 || M % 256 || N % 256 || K % 64 || K < 128 || N > 2048 || repeats < 1) return fail(PG_ERR_INVALID, "pg_dbg_gemm_resid_ln: shape");
-  DeviceGuard g(-1);
-  int rc = dbg_device(device);
-  if (rc) return rc;
-  Tmp t;
-  float* tmp = (float*)t.get((size_t)std::max((size_t)M * K, (size_t)N * K) * 4);
-  bf16_t* ba = (bf16_t*)t.get((size_t)M * K * 2);
-  bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2);
-  float* db = (float*)t.get((size_t)N * 4);
-  float* dg = (float*)t.get((size_t)N * 4);
-  float* dbt = (float*)t.get((size_t)N * 4);
-  float* dx = (float*)t.get((size_t)M * N * 4);
-  float* dx0 = (float*)t.get((size_t)M * N * 4);
-  bf16_t* h1 = (bf16_t*)t.get((size_t)M * N * 2);
-  bf16_t* h2 = (bf16_t*)t.get((size_t)M * N * 2);
-  float* hf = (float*)t.get((size_t)M * N * 4);
-  int* cnt = (int*)t.get((size_t)(M / 64 + 8) * 4);           // zero-filled by Tmp::get
-  if (!tmp || !ba || !bw || !db || !dg || !dbt || !dx || !dx0 || !h1 || !h2 || !hf || !cnt) return fail(PG_ERR_HIP, "hipMalloc failed");
-  PG_HIP(hipMemcpy(tmp, a, (size_t)M * K * 4, hipMemcpyHostToDevice));
-  if ((rc = launch_f32_to_bf16(nullptr, tmp, ba, (int64_t)M * K, 1.f))) return rc;
-  PG_HIP(hipDeviceSynchronize());
-  PG_HIP(hipMemcpy(tmp, w, (size_t)N * K * 4, hipMemcpyHostToDevice));
-  if ((rc = launch_f32_to_bf16(nullptr, tmp, bw, (int64_t)N * K, 1.f))) return rc;
-  PG_HIP(hipMemcpy(db, bias, (size_t)N * 4, hipMemcpyHostToDevice));
-  PG_HIP(hipMemcpy(dg, gamma, (size_t)N * 4, hipMemcpyHostToDevice));
-  PG_HIP(hipMemcpy(dbt, beta, (size_t)N * 4, hipMemcpyHostToDevice));
-  PG_HIP(hipMemcpy(dx0, resid_inout, (size_t)M * N * 4, hipMemcpyHostToDevice));
-  EpiAux aux{};
-  aux.h = h1;
-  aux.gamma = dg;
-  aux.beta = dbt;
-  aux.counters = cnt;
-  aux.eps = eps;
-  // repeated launches: the arrival counters must reset themselves, and who arrives last varies from launch to launch
-  if (!gemm_big_can_fuse_ln(M, N, K)) return fail(PG_ERR_UNSUPPORTED, "pg_dbg_gemm_resid_ln: a row panel's tiles would span XCDs at this shape");
-  for (int r = 0; r < repeats; ++r) {
-    PG_HIP(hipMemcpyAsync(dx, dx0, (size_t)M * N * 4, hipMemcpyDeviceToDevice, nullptr));
-    PG_HIP(hipMemsetAsync(h1, 0xff, (size_t)M * N * 2, nullptr));
-    if ((rc = launch_gemm_big(nullptr, ba, bw, db, dx, M, N, K, K, K, N, EPI_F32_RESID_LN, &aux))) return rc;
-  }
-  if ((rc = launch_layernorm_bf16(nullptr, dx, dg, dbt, h2, M, N, eps))) return rc;      // the stand-alone kernel on the same rows
-  if ((rc = launch_bf16_to_f32(nullptr, h1, hf, (int64_t)M * N))) return rc;
-  PG_HIP(hipDeviceSynchronize());
-  PG_HIP(hipMemcpy(h_fused, hf, (size_t)M * N * 4, hipMemcpyDeviceToHost));
-  if ((rc = launch_bf16_to_f32(nullptr, h2, hf, (int64_t)M * N))) return rc;
-  PG_HIP(hipDeviceSynchronize());
-  PG_HIP(hipMemcpy(h_kernel, hf, (size_t)M * N * 4, hipMemcpyDeviceToHost));
-  PG_HIP(hipMemcpy(resid_inout, dx, (size_t)M * N * 4, hipMemcpyDeviceToHost));
-  std::vector<int> c((size_t)M / 64 + 8);
-  PG_HIP(hipMemcpy(c.data(), cnt, c.size() * 4, hipMemcpyDeviceToHost));
-  for (int v : c)
-    if (v != 0) return fail(PG_ERR_HIP, "pg_dbg_gemm_resid_ln: an arrival counter did not return to zero");
-  return PG_OK;
-}
-
 int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int iters, double* avg_ms) {
   if (!avg_ms || M % 16 || (M > 256 && M % 64) || N % 64 || K % 64 || iters < 1) return fail(PG_ERR_INVALID, "pg_dbg_gemm_bench: bad argument");
   DeviceGuard g(-1);

@@ -64,9 +64,7 @@ struct Engine {
   // workspace (grow-only)
   DevBuf x, h, qkv, ctx, ffn, sel_h, sel_g, logits, d_tokens, d_idx, d_samp_tok, d_samp_logits, d_rowmap, scratch;
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
-  DevBuf ln_counters;                      // LayerNorm inside the residual GEMMs: arrival counters per row panel (self-resetting)
-  bool fuse_ln = false;                    // PGIBBS_LN_FUSE=1: LayerNorm inside the residual GEMMs (bit-identical results; measured slower)
-  // x (+)= a W^T + b, then h = LayerNorm(x; ln): one launch when the big-tile kernel takes the shape, else GEMM + LayerNorm kernel
+  // x (+)= a W^T + b, then h = LayerNorm(x; ln): residual GEMM + LayerNorm kernel
   int resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
                     float* ws = nullptr, size_t ws_bytes = 0);
   DevBuf tmp_idx, tmp_out;                 // batched generate_single on small MSAs: one template's step table / outputs

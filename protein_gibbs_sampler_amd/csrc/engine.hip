@@ -94,7 +94,7 @@ Engine::~Engine() {
   if (device >= 0) (void)hipSetDevice(device);
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
-                    &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &ln_counters, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
+                    &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
   for (DevBuf* b : bufs) b->release();
   prof.destroy();
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -183,12 +183,6 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
     if (tensors[i].name) tm.m[tensors[i].name] = &tensors[i];
   Uploader up{this, &tm, ""};
   const int d = cfg.d_model, f = cfg.d_ffn, V = cfg.vocab;
-  {
-    // LayerNorm inside the residual GEMMs (gemm_epilogue.h): bit-identical with the stand-alone kernel, but measured SLOWER
-    // (config 2: 91.5 vs 87.8 ms per iteration; config 4: 153.7 vs 150.4) -- off unless PGIBBS_LN_FUSE=1
-    const char* ev = getenv("PGIBBS_LN_FUSE");
-    fuse_ln = ev ? atoi(ev) != 0 : false;
-  }
   const float qs = 0.125f;  // head_dim^-0.5 = 64^-0.5, folded into W_q and b_q (exact in bf16)
   bool ok = true;
   ok = ok && (embed = up.f32("embed_tokens.weight", (int64_t)V * d));
@@ -381,29 +375,12 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   return PG_OK;
 }
 
-// x[M_rows][d] += a[M_rows][K] W^T + b, then h = LayerNorm(x; ln) as the next GEMM's bf16 operand.  Big batches: ONE launch --
-// the residual GEMM's workgroup that completes a row panel normalises it (gemm_epilogue.h) --, otherwise the GEMM the dispatch
-// picks followed by the LayerNorm kernel.  Both forms run the same per-row LayerNorm code on the same fp32 rows: identical bits,
-// so the choice is purely local (no shard-invariance concern).
+// x[M_rows][d] += a[M_rows][K] W^T + b, then h = LayerNorm(x; ln) as the next GEMM's bf16 operand: the residual GEMM the dispatch
+// picks, followed by the LayerNorm kernel at its HBM roofline.  (Normalising inside the GEMM was built in round 3, bit-identical
+// and slower; it left the library in round 4: tools/probes/gemm_ln_fused.hip.)
 int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
                           float* ws, size_t ws_bytes) {
   const int d = W.N, K = W.K;
-  const bool big = fuse_ln && M_rows % 256 == 0 && d % 256 == 0 && K >= 128 && K % 64 == 0 &&
-                   (long)(M_rows / 256) * (d / 256) >= 128 &&      // the shapes launch_gemm_bf16 gives to the big-tile kernels
-                   gemm_big_can_fuse_ln(M_rows, d, K);              // ... with every row panel's tiles on one XCD
-  if (big) {
-    int rc = ln_counters.ensure((size_t)(M_rows / 64 + 8) * 4, stream);
-    if (rc) return rc;
-    EpiAux aux{};
-    aux.h = h;
-    aux.gamma = ln.g;
-    aux.beta = ln.b;
-    aux.counters = ln_counters.as<int>();
-    aux.eps = cfg.layer_norm_eps;
-    static const int ln_flags = [] { const char* e = getenv("PGIBBS_LN_FLAGS"); return e ? atoi(e) : 0; }();
-    aux.flags = ln_flags;
-    return timed(PC_GEMM, [&] { return launch_gemm_big(stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID_LN, &aux); });
-  }
   int rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
   if (rc) return rc;
   return timed(PC_LN, [&] { return launch_layernorm_bf16(stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps); });

@@ -165,15 +165,13 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(rsrc_t rs, int voff, int soff) {
 // Stores keep the row step in the VGPR offset: with an SGPR soffset the compiler's hazard recogniser assumes a 128-bit
 // store's data registers may be overwritten by the very next VALU instruction, and on gfx950 that corrupted the last
 // dword of the stored row (seen as wrong .w components in lanes 12-15 of each 16) -- with soffset = 0 it pads the hazard.
-__device__ __forceinline__ void buf_store_f32x4(f32x4 v, rsrc_t rs, int voff, int row_off, bool stream = true) {
-  if (stream) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, PG_EPI_AUX);
-  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, 0);
+__device__ __forceinline__ void buf_store_f32x4(f32x4 v, rsrc_t rs, int voff, int row_off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, voff + row_off, 0, PG_EPI_AUX);
 }
 
 template <int EPI, bool NO_STORE = false>
 __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int wm, int wn, int wave, int lane, int m0,
-                                             int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo,
-                                             const EpiAux& aux) {
+                                             int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo) {
   const int fr = lane & 15, fq = lane >> 4;
   __syncthreads();
   // fp32-staged epilogues (fp32 outputs, and fc1's bf16+GELU).  Two phases; in phase p EVERY wave stages its accumulator
@@ -181,7 +179,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
   // staged rows w*16.. = token rows m0 + (w>>2)*128 + (4p + (w&3))*16 + it and moves them out as whole 1-KiB rows.
   // Residual variant: the 16 row loads of a phase (64 VGPRs) are issued BEFORE that phase's LDS staging, and phase 1's
   // loads before phase 0's stores, so a tile exposes about one memory latency instead of four.
-  if (EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN) {
+  if (EPI == EPI_BF16_GELU || EPI == EPI_F32 || EPI == EPI_F32_GELU || EPI == EPI_F32_RESID) {
     auto stage = [&](int p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -225,7 +223,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       }
       return;
     }
-    if (EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN) {
+    if (EPI == EPI_F32_RESID) {
       // Row-shaped accesses as buffer ops: wave-uniform row base in the resource, the row step in an SGPR offset, one
       // VGPR (lane*16) for all 64 accesses -- 64-bit per-row VGPR addresses would not leave room for 32 rows in flight.
       const rsrc_t rs0 = row_rsrc((float*)out + (size_t)grow(0) * ldo + n0);
@@ -245,7 +243,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep, !(aux.flags & 1));
+        buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep);
       }
       __syncthreads();
       stage(1);
@@ -254,7 +252,7 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
       for (int it = 0; it < 16; ++it) {
         const int sr = wave * 16 + it;
         const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
-        buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep, !(aux.flags & 1));
+        buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep);
       }
       return;
     }
@@ -324,21 +322,20 @@ template <int EPI, int ABL = 0, int GM = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
                                                           int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
-                                                          int tail_m0, EpiAux aux) {
+                                                          int tail_m0) {
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
   // n_tail > 0: they are the FIRST workgroups of the grid; n_tail < 0: the LAST |n_tail| (PGIBBS_GEMM_TAIL_LAST)
   const int nt_abs = n_tail < 0 ? -n_tail : n_tail;
   if (ABL == 0 && nt_abs && (n_tail > 0 ? (int)blockIdx.x < nt_abs : (int)blockIdx.x >= n_tiles)) {
-    // workgroup b runs on XCD b % 8: all column tiles of a 64-row block go to one XCD (its L2 is where a fused LayerNorm meets
-    // the rows, gemm_epilogue.h) whenever the row blocks divide by 8 (tail rows are multiples of 256: at least by 4)
+    // workgroup b runs on XCD b % 8: all column tiles of a 64-row block go to one XCD (they share the block's X rows through its
+    // L2) whenever the row blocks divide by 8 (tail rows are multiples of 256: at least by 4)
     const int tn64 = tiles_n * 4, bt = n_tail > 0 ? blockIdx.x : blockIdx.x - n_tiles, n_rb = nt_abs / tn64;
     int rb, tn;
     if ((n_rb & 7) == 0) { const int j = bt >> 3; rb = (j / tn64) * 8 + (bt & 7); tn = j % tn64; }
     else { rb = bt / tn64; tn = bt % tn64; }
-    gemm_tail_tile64<8, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + rb * 64, tn * 64, smem,
-                             n_tiles / tiles_n + rb, aux);             // LayerNorm counters: after the panels of the big tiles
+    gemm_tail_tile64<8, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + rb * 64, tn * 64, smem);
     return;
   }
 
@@ -469,11 +466,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo, aux);
-  if (EPI == EPI_F32_RESID_LN) {     // the last of the panel's column tiles normalises its 256 rows (gemm_epilogue.h)
-    __syncthreads();                 // the staging LDS is free (flag word)
-    ln_when_panel_complete<8>(aux, tile_m, tiles_n, (const float*)out + (size_t)m0 * ldo, m0, 256, ldo, (int*)smem);
-  }
+  epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
 }
 
 // Measured alternatives that were NOT faster on MI355X and were removed again (QKV GEMM, M=66048 N=3840 K=1280, steady-state
@@ -499,16 +492,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 // without any epilogue at 1245-1273 TFLOP/s.
 // M rows of 256 x 256 tiles (M may be 0) + tail_rows rows of 64 x 64 tail tiles starting at row M, one grid
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0, const EpiAux* aux = nullptr) {
+                     int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   static const int tail_last = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_LAST"); return e ? atoi(e) : 0; }();
   const int n_tail_abs = (tail_rows / 64) * (N / 64), tail_m0 = M;
-  const int n_tail = (tail_last && epi != EPI_F32_RESID_LN) ? -n_tail_abs : n_tail_abs;
-  EpiAux ax = aux ? *aux : EpiAux{};
-  static const int plain_stores = [] { const char* e = getenv("PGIBBS_RESID_PLAIN_STORES"); return e ? atoi(e) : 0; }();
-  if (plain_stores) ax.flags |= 1;
+  const int n_tail = tail_last ? -n_tail_abs : n_tail_abs;
   dim3 grid(n_tiles + n_tail_abs), block(512);
-#define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax
+#define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0
   if (abl) {   // ablations: EPI_BF16 only
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, PG_PP_ARGS);
     if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, PG_PP_ARGS);
@@ -548,7 +538,6 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
     PG_GEMM_CASE(EPI_BF16)
     PG_GEMM_CASE(EPI_BF16_GELU)
     PG_GEMM_CASE(EPI_F32_RESID)
-    PG_GEMM_CASE(EPI_F32_RESID_LN)
     PG_GEMM_CASE(EPI_F32)
     PG_GEMM_CASE(EPI_F32_GELU)
     default:
@@ -582,36 +571,21 @@ void gemm_big_geometry(int M, int N, int K, int* m_main_panels, int* tail_rows) 
   *m_main_panels = g.m_main;
   *tail_rows = g.tail_rows;
 }
-// EPI_F32_RESID_LN needs every row panel's column tiles on one XCD (gemm_epilogue.h): XCD x owns the contiguous tile range
-// [x q + min(x, r), ...) of the grouped order, a group being gm m-panels x all n-tiles -- so every range must begin on a group
-// boundary; tail row blocks must divide by 8.
-bool gemm_big_can_fuse_ln(int M, int N, int K) {
-  if (M % 256 || N % 256 || K % 64 || K < 128 || M < 256 || N > 2048) return false;
-  const BigGeom g = big_geometry(M, N, K);
-  const int tiles_n = N / 256, n_tiles = g.m_main * tiles_n, gsz = g.gm * tiles_n;
-  const int q = n_tiles >> 3, r = n_tiles & 7;
-  for (int x = 1; x < 8; ++x)
-    if ((x * q + (x < r ? x : r)) % gsz) return false;
-  return ((g.tail_rows / 64) & 7) == 0;
-}
-
 // The big-batch GEMM: whole rounds of 256 x 256 tiles (one per CU) plus, in the SAME grid, 64 x 64 tail tiles for the rows
 // beyond the last full round when that round would be mostly empty (gemm_epilogue.h).  Kernel per epilogue: the 16-wave kernel
 // for the bf16 outputs (QKV projections: 3.5-4 % faster there; fc1: its one-pass GELU epilogue is 0.03 ms shorter per launch),
 // the 8-wave ping-pong kernel for the fp32 outputs (the 16-wave kernel loses 3-4 % on the residual read-modify-write);
 // PGIBBS_GEMM_BIG=pp / w16 forces one kernel for the plain epilogues.  M, N multiples of 256, K a multiple of 64, K >= 128.
 int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
-                    int ldw, int ldo, int epi, const EpiAux* aux) {
+                    int ldw, int ldo, int epi) {
   if (M % 256 || N % 256 || K % 64 || K < 128 || M < 256) return fail(1, "gemm_big: shape");
   static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? 16 : 0); }();
   const BigGeom geo = big_geometry(M, N, K);
   const int m_main = geo.m_main, tail_rows = geo.tail_rows;
   const bool bf16out = epi == EPI_BF16 || epi == EPI_BF16_GELU;
-  const bool use16 = epi != EPI_F32_RESID_LN && (big == 16 || (big == -1 && bf16out));
-  if (epi == EPI_F32_RESID_LN && (!aux || N != ldo || !gemm_big_can_fuse_ln(M, N, K)))
-    return fail(1, "gemm_big: the LayerNorm epilogue needs its operands, whole rows (N == ldo) and a row panel's tiles on one XCD");
-  if (use16) return launch_gemm_w16(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows, aux);
-  return launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows, aux);
+  const bool use16 = big == 16 || (big == -1 && bf16out);
+  if (use16) return launch_gemm_w16(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows);
+  return launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1033,7 +1007,7 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
     if (ok256) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
     if (ok128) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   }
-  if (ok256 && t256 >= 128) return launch_gemm_big(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, nullptr);
+  if (ok256 && t256 >= 128) return launch_gemm_big(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   if (ok128 && (t128 >= 200 || !(M % 64 == 0))) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }

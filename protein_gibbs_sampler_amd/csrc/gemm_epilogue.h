@@ -2,7 +2,6 @@
 // (one definition for all kernels) and the LDS-staged epilogue of the 256 x 256 tiles with 4 or 16 waves.
 #pragma once
 #include "kernels.h"
-#include "ln_row.h"
 
 namespace pg {
 
@@ -59,54 +58,11 @@ __device__ __forceinline__ uint32_t gelu_bf16out_pack2(float x0, float x1) {
 
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm inside the residual GEMM (EPI_F32_RESID_LN).  x += ctx W^T + b is followed, in the forward pass, by h = LN(x): a
-// kernel that re-reads from HBM the 338 MB the GEMM has just written (config 2: 85 us, 66 times per iteration, at the HBM
-// roofline -- pure avoidable traffic).  A row can only be normalised when all of its column tiles are done, so every workgroup,
-// after storing its tile, counts itself into a per-row-panel counter; the LAST one to arrive for a panel normalises that
-// panel's rows -- one wave per row, the very code of the stand-alone kernel (ln_row.h), so h is bit-identical with the unfused
-// path and results do not depend on which workgroup happens to be last, nor on whether a launch fuses at all.
-// Coherence without cache maintenance: the launcher fuses only when all column tiles of a panel run on ONE XCD (the grouped
-// tile order puts them there; checked on the host, else the LayerNorm kernel follows as before).  The XCD's CUs share its L2,
-// which is therefore the coherence point: a writer's stores are acknowledged by L2 (s_waitcnt vmcnt(0)) before it counts
-// itself in, the counter is an L2 atomic, and the normalising workgroup reads the rows with sc0 loads (past its own L1).  An
-// agent-scope release / acquire pair instead (buffer_wbl2 / buffer_inv sc1 per tile) writes back and invalidates the whole L2
-// under the other CUs' main loops: measured 121 vs 90 ms per iteration.
-// Counters reset themselves (the last arriver stores 0), so a zero-filled array serves every launch.
-// ---------------------------------------------------------------------------------------------------------------------
-struct EpiAux {
-  bf16_t* h;               // LayerNorm output rows [M][d] bf16 (the next GEMM's operand)
-  const float* gamma;      // the FOLLOWING LayerNorm's weight / bias [d]
-  const float* beta;
-  int* counters;           // one per 256-row panel of 256 x 256 tiles, then one per 64-row block of tail tiles; zero between launches
-  float eps;
-  int flags;               // experiments (PGIBBS_LN_FLAGS): 1 = the residual rows leave with ordinary (not streaming) stores
-};
-
 template <int EPI> struct EpiTraits {
   static constexpr bool bf16out = EPI == EPI_BF16 || EPI == EPI_BF16_GELU;
   static constexpr bool gelu_bf16 = EPI == EPI_BF16_GELU;
-  static constexpr bool resid = EPI == EPI_F32_RESID || EPI == EPI_F32_RESID_LN;
+  static constexpr bool resid = EPI == EPI_F32_RESID;
 };
-
-// Called by every thread of a workgroup after its tile's stores: counts the workgroup into counters[slot]; the workgroup that
-// completes the n_tiles of the row block normalises its n_rows rows (x_rows = first row of the block, row length d = ldo).
-template <int NW>
-__device__ __forceinline__ void ln_when_panel_complete(const EpiAux& aux, int slot, int n_tiles, const float* x_rows, int64_t row0,
-                                                       int n_rows, int d, int* flag /* LDS word */) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my stores of the residual tile are in the XCD's L2
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int prev = __hip_atomic_fetch_add(aux.counters + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = prev == n_tiles - 1;
-    if (last) __hip_atomic_store(aux.counters + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag = last;
-  }
-  __syncthreads();
-  if (!*flag) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  ln_rows_l2<4>(x_rows, d, aux.h + (size_t)row0 * d, n_rows, wave, NW, d, aux.eps, aux.gamma, aux.beta, lane);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 64 x 64 "tail" tile computed by a whole 8- or 16-wave workgroup of the 256 x 256 kernels.  1290 tiles on 256 CUs are
@@ -123,7 +79,7 @@ __device__ __forceinline__ void ln_when_panel_complete(const EpiAux& aux, int sl
 template <int NW, int EPI, bool SPLIT3 = false>
 __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                  const float* __restrict__ bias, void* __restrict__ out, int K, int ldx, int ldw,
-                                                 int ldo, int m0, int n0, char* smem, int ln_slot, const EpiAux& aux) {
+                                                 int ldo, int m0, int n0, char* smem) {
   static_assert(NW == 8 || NW == 16, "tail tile: 8 or 16 waves");
   constexpr int STAGES = 8, STAGE_BYTES = 16384, PPW = 16 / NW, TM = 16 / NW;
   typedef EpiTraits<EPI> T;
@@ -236,8 +192,6 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
       *(float4*)((float*)out + o) = make_float4(v0, v1, v2, v3);
     }
   }
-  if (EPI == EPI_F32_RESID_LN)     // the last of the row block's N / 64 tiles normalises its 64 rows
-    ln_when_panel_complete<NW>(aux, ln_slot, ldo / 64, (const float*)out + (size_t)m0 * ldo, m0, 64, ldo, (int*)smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -49,14 +49,14 @@ template <int EPI, int GM, int ABL>
 __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                                const float* __restrict__ bias, void* __restrict__ out, int K,
                                                                int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
-                                                               int tail_m0, EpiAux aux) {
+                                                               int tail_m0) {
   __shared__ __attribute__((aligned(16))) char smem[2 * W16_KSLOT];
 
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
   const int nt_abs = n_tail < 0 ? -n_tail : n_tail;       // n_tail < 0: the tail workgroups are the LAST of the grid
   if (ABL == 0 && nt_abs && (n_tail > 0 ? (int)blockIdx.x < nt_abs : (int)blockIdx.x >= n_tiles)) {
     const int tn64 = tiles_n * 4, bt = n_tail > 0 ? blockIdx.x : blockIdx.x - n_tiles;
-    gemm_tail_tile64<16, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, 0, aux);
+    gemm_tail_tile64<16, EPI>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
     const int out_cols = EPI == EPI_SPLIT3_GELU ? ldo / 3 : ldo;
     const int tn64 = tiles_n * 4, bt = blockIdx.x;
     (void)out_cols;
-    gemm_tail_tile64<16, EPI, true>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem, 0, EpiAux{});
+    gemm_tail_tile64<16, EPI, true>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -311,19 +311,18 @@ template <int ABL>
 static int launch_w16_abl(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int K, int ldx, int ldw,
                           int ldo, int tiles_n, int n_tiles) {
   hipLaunchKernelGGL((gemm_bf16_w16_kernel<EPI_BF16, 4, ABL>), dim3(n_tiles), dim3(1024), 0, s, X, W, bias, out, K, ldx, ldw, ldo,
-                     tiles_n, n_tiles, 0, 0, EpiAux{});
+                     tiles_n, n_tiles, 0, 0);
   PG_HIP(hipGetLastError());
   return 0;
 }
 
 // M, N multiples of 256; K a multiple of 64.  abl > 0: micro-benchmark variants (bf16 epilogue only)
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
-                    int ldw, int ldo, int epi, int abl, int tail_rows, const EpiAux* aux) {
+                    int ldw, int ldo, int epi, int abl, int tail_rows) {
   const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   static const int tail_last = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_LAST"); return e ? atoi(e) : 0; }();
   const int n_tail_abs = (tail_rows / 64) * (N / 64), tail_m0 = M;
   const int n_tail = tail_last ? -n_tail_abs : n_tail_abs;
-  const EpiAux ax = aux ? *aux : EpiAux{};
   if (M % 256 || N % 256 || K % 64 || K < 64 || tail_rows % 64 || n_tiles + n_tail_abs < 1) return fail(1, "gemm_w16: shape");
   switch (abl) {
     case 0: break;
@@ -339,8 +338,8 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
   dim3 grid(n_tiles + n_tail_abs), block(1024);
 #define PG_W16_CASE(E)                                                                                                     \
   case E:                                                                                                                  \
-    if (gm == 2) hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 2, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax); \
-    else hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 4, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, ax);     \
+    if (gm == 2) hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 2, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0); \
+    else hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 4, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0);     \
     break;
   switch (epi) {
     PG_W16_CASE(EPI_BF16)

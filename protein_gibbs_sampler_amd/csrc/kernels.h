@@ -12,9 +12,7 @@ struct SeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_GELU = 4,
        EPI_F32_PARTIAL = 5 /* internal: split-K partial sums, no bias */,
-       EPI_SPLIT3_GELU = 6 /* strict mode fc1: erf-GELU, then the bf16 operand rows [lo | hi | hi] (ldo = 3 N) that fc2 reads; 16-wave kernel only */,
-       EPI_F32_RESID_LN = 7 /* residual update; the last column tile of a row panel to finish also writes h = LayerNorm(x) of the
-                               panel's rows (gemm_epilogue.h, EpiAux) -- the 8-wave tile kernel only */ };
+       EPI_SPLIT3_GELU = 6 /* strict mode fc1: erf-GELU, then the bf16 operand rows [lo | hi | hi] (ldo = 3 N) that fc2 reads; 16-wave kernel only */ };
 
 // out[M][N] (+)= X[M][K] . W[N][K]^T + bias.  M a multiple of 16 up to 256 rows, of 128 beyond; N a multiple of 64; K of 64
 // (activation buffers are padded to 256 rows: kernels may touch the padding rows of the last tile).
@@ -32,18 +30,15 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
 bool gemm_ln_skinny_ok(int M, int N, int K);
 int launch_gemm_ln_skinny(hipStream_t s, const float* X, int ldx, const float* gamma, const float* beta, float eps, const bf16_t* W,
                           const float* bias, void* out, int M, int N, int K, int ldw, int ldo, int epi);
-struct EpiAux;       // gemm_epilogue.h: operands of the LayerNorm-folding epilogues
 // the big-batch GEMM: whole rounds of 256 x 256 tiles + 64 x 64 tail tiles in one grid (gemm_bf16.hip); M, N multiples of 256
 int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
-                    int ldw, int ldo, int epi, const EpiAux* aux = nullptr);
+                    int ldw, int ldo, int epi);
 // its split of the rows: m-panels of 256 x 256 tiles (whole rounds of one tile per CU) + rows of 64 x 64 tail tiles
 void gemm_big_geometry(int M, int N, int K, int* m_main_panels, int* tail_rows);
-// may a launch_gemm_big(..., EPI_F32_RESID_LN) of this shape normalise inside the GEMM? (every row panel's tiles on one XCD)
-bool gemm_big_can_fuse_ln(int M, int N, int K);
 // the 16-wave 256x256 tile kernel (gemm_w16.hip): M (may be 0 with tail_rows > 0), N multiples of 256, K a multiple of 64;
 // tail_rows rows of 64 x 64 tail tiles from row M on
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
-                    int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0, const EpiAux* aux = nullptr);
+                    int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0);
 // strict mode: the three split-bf16 products of a projection in one pass (gemm_w16.hip); X3 / W3 in the split operand layout,
 // K = logical depth; bit-identical with launch_gemm_bf16 over K' = 3K on the same operands
 int launch_gemm_split3(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K, int ldo,

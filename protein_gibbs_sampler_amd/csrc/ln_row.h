@@ -70,38 +70,4 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kM
     }
 }
 
-// rows r = first, first + step, ... < n_rows of a row block: x fp32 [.][ldx] -> LayerNorm -> h bf16 [.][d] (3 d with split3);
-// one wave per row, RB rows in flight per wave (the loop is latency-bound: 256 rows on 8 waves are 32 round trips to L2 / HBM
-// one row at a time).  The rows were written by OTHER CUs of this XCD a moment ago (gemm_epilogue.h): they are read with
-// sc0 = 1, i.e. past this CU's vector L1 from the L2 the XCD shares.
-template <int RB>
-__device__ __forceinline__ void ln_rows_l2(const float* __restrict__ x, int64_t ldx, bf16_t* __restrict__ h, int n_rows, int first,
-                                           int step, int d, float eps, const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, int lane, bool split3 = false) {
-  typedef float pg_f32x4_t __attribute__((ext_vector_type(4)));
-  const int nch4 = d >> 2;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7fffffff, 0x00020000);
-  for (int r0 = first; r0 < n_rows; r0 += step * RB) {
-    float4 v[RB][kMaxCh];
-#pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      const int r = r0 + u * step;
-#pragma unroll
-      for (int i = 0; i < kMaxCh; ++i)
-        if (r < n_rows && lane + 64 * i < nch4) {
-          const pg_f32x4_t q = __builtin_bit_cast(pg_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((int64_t)r * ldx * 4) + (lane + 64 * i) * 16, 0, 1 /* sc0 */));
-          v[u][i] = make_float4(q[0], q[1], q[2], q[3]);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      const int r = r0 + u * step;
-      if (r < n_rows) {
-        ln_inplace(v[u], nch4, lane, d, eps, gamma, beta);
-        store_row_bf16(h + (size_t)r * d * (split3 ? 3 : 1), v[u], nch4, lane, split3);
-      }
-    }
-  }
-}
-
 }  // namespace pg
