@@ -183,6 +183,7 @@ class ESM_MSA_sampler():
             t = torch.from_numpy(mine)
             on_gpu = ctx.dist.get_backend() != "gloo"
             full = sharding.gather_tokens(ctx.dist, t.to(self.device) if on_gpu else t, counts).cpu().numpy()
+            self.last_run = []                    # per-draw records are refused together with sharding (above)
             return ["".join(self.model.alphabet.get_tok(int(v)) for v in full[j, 1:jobs[j]["batch"].shape[2]]) for j in range(n)]
         if not self.record:
             self.last_run = []

@@ -16,7 +16,7 @@ import tempfile
 import textwrap
 import warnings
 
-from . import models
+from . import models, sharding
 from ._cli import RawAndDefaultsFormatter, add_engine_args, seed_everything
 from .esm_msa_sampler import ESM_MSA_sampler
 from .fasta_io import parse_fasta, write_sequential_fasta
@@ -45,12 +45,12 @@ def build_template_alignment(template_name, template_seq, reference_seqs, refere
     return alignment, apply_gap_threshold(alignment, gap_percent_threshold), 0
 
 
-def _is_rank0():
-    try:
-        import torch.distributed as dist
-        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
-    except ImportError:
-        return True
+def _writes_output(sampler):
+    """Every process writes its own `output_path` -- unless ONE job is being split over the torch.distributed ranks
+    (sampler.shard_over_ranks / PGIBBS_SHARD_OVER_RANKS with world size > 1): every rank then holds the full result and rank 0
+    writes it.  A process group that merely exists (each rank sampling its OWN templates) does not silence anybody."""
+    ctx = sharding.dist_context() if sharding.sharding_requested(getattr(sampler, "shard_over_ranks", False)) else None
+    return ctx is None or ctx.rank == 0
 
 
 def pgen_msa(templates_path, references_path, output_path, seqs_per_template, keep_identical, steps, passes, burn_in, device,
@@ -65,29 +65,46 @@ def pgen_msa(templates_path, references_path, output_path, seqs_per_template, ke
     with tempfile.NamedTemporaryFile(delete=False, mode="w") as tmp:
         write_sequential_fasta(tmp, references)
         reference_db_path = tmp.name
+    writer = _writes_output(sampler)
+    ctx = sharding.dist_context() if sharding.sharding_requested(getattr(sampler, "shard_over_ranks", False)) else None
+    # jobs per generate_single_batch call: `template_batch` alignments share a forward; a sharded run hands every rank that many
+    chunk_jobs = max(1, template_batch) * (ctx.world if ctx is not None else 1)
+    outfile = open(output_path, "w") if writer else None
     try:
         reference_seqs = dict(zip(*parse_fasta(reference_db_path, return_names=True)))
-        # The reference calls generate_single once per template and requested sequence, in this order
-        # (/root/reference/src/pgen/pgen_msa_revised.py:107-115).  Building the alignments consumes no interpreter RNG, so all of
-        # them are built first and the whole list of (template, i) jobs goes to generate_single_batch: same RNG consumption and
-        # strings as the serial loop, equal-shape alignments share forwards (`template_batch` per call), and with
-        # sampler.shard_over_ranks the list is split over the torch.distributed ranks (rank 0 writes the file).
-        names, msas, excludes, row = [], [], [], 0
+        # The reference calls generate_single once per template and requested sequence, in this order, and prints each sequence
+        # as soon as it exists (/root/reference/src/pgen/pgen_msa_revised.py:107-115, flush=True).  Here the (template, i) jobs are
+        # collected in that order and handed to generate_single_batch a CHUNK at a time: the interpreter RNG (one shuffle per
+        # MSA and pass, MSA-major) and the torch draw seeds (one per MSA, in order) are consumed exactly as in the serial loop,
+        # so the strings are the same for any chunk size; equal-shape alignments of a chunk share forwards; with
+        # sampler.shard_over_ranks a chunk is split over the torch.distributed ranks.  After every chunk the finished records
+        # are appended and flushed: a failure on a late template (phmmer, mafft, out of memory) loses that chunk only.
+        pending = []                                    # (name, alignment, excluded columns)
+        row = -1 if legacy else 0
+
+        def flush_pending():
+            if not pending:
+                return
+            new_seqs = sampler.generate_single_batch([p[1] for p in pending], steps=steps, passes=passes, burn_in=burn_in, k=top_k,
+                                                     target_index=row, exclude_positions=[p[2] for p in pending],
+                                                     max_batch=template_batch)
+            if outfile is not None:
+                for (name, _, _), new_seq in zip(pending, new_seqs):
+                    print(f">{name}\n{new_seq.replace('-', '')}", file=outfile, flush=True)
+            del pending[:]
+
         for template_name, template_seq in templates:
             alignment, exclude_positions, row = build_template_alignment(
                 template_name, template_seq, reference_seqs, reference_db_path, alignment_size, keep_identical, ep, op,
                 legacy, gap_percent_threshold, debug)
             for i in range(seqs_per_template):
-                names.append(f"{i}_{template_name}")
-                msas.append(alignment)
-                excludes.append(exclude_positions)
-        new_seqs = sampler.generate_single_batch(msas, steps=steps, passes=passes, burn_in=burn_in, k=top_k, target_index=row,
-                                                 exclude_positions=excludes, max_batch=template_batch) if msas else []
-        if _is_rank0():
-            with open(output_path, "w") as outfile:
-                for name, new_seq in zip(names, new_seqs):
-                    print(f">{name}\n{new_seq.replace('-', '')}", file=outfile, flush=True)
+                pending.append((f"{i}_{template_name}", alignment, exclude_positions))
+                if len(pending) >= chunk_jobs:
+                    flush_pending()
+        flush_pending()
     finally:
+        if outfile is not None:
+            outfile.close()
         os.unlink(reference_db_path)
 
 

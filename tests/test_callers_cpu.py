@@ -177,3 +177,62 @@ def test_tool_wrappers_with_mocked_subprocess(monkeypatch, tmp_path):
     monkeypatch.setattr(subprocess, "run", lambda argv, **kw: Res("boom", rc=2))
     with pytest.raises(SystemExit):
         msa_tools.run_phmmer("MKVA", tmp_path / "db.fasta")
+
+
+class _RecordingSampler:
+    """generate_single_batch stand-in: returns the first row of every alignment upper-cased and records the calls."""
+    shard_over_ranks = False
+
+    def __init__(self, fail_on_call=None):
+        self.calls, self.fail_on_call = [], fail_on_call
+
+    def generate_single_batch(self, msas, **kw):
+        self.calls.append((len(msas), kw["target_index"], kw["max_batch"]))
+        if self.fail_on_call is not None and len(self.calls) - 1 == self.fail_on_call:
+            raise RuntimeError("out of memory (simulated)")
+        return [m[kw["target_index"]] for m in msas]
+
+
+def _run_pgen_msa_revised(tmp_path, monkeypatch, sampler, n_templates=5, seqs_per_template=2, template_batch=4):
+    from _standin import fake_generate_alignment, fake_run_phmmer
+    monkeypatch.setattr(pgen_msa_revised, "run_phmmer", fake_run_phmmer)
+    monkeypatch.setattr(pgen_msa_revised, "generate_alignment", fake_generate_alignment)
+    t, r, o = tmp_path / "t.fasta", tmp_path / "r.fasta", tmp_path / "o.fasta"
+    t.write_text("".join(">t%d\nMKV%sLA\n" % (i, "ACDEF"[i % 5]) for i in range(n_templates)))
+    r.write_text(">a\nMKVALA\n>b\nMKVCLA\n>c\nMRVDLA\n")
+    pgen_msa_revised.pgen_msa(str(t), str(r), str(o), seqs_per_template, True, 3, 1, 1, "cuda:0", "esm_msa1", 3, 0.0, 1.53, 1,
+                              legacy=True, sampler=sampler, template_batch=template_batch)
+    return o
+
+
+def test_pgen_msa_revised_writes_chunk_by_chunk(tmp_path, monkeypatch):
+    """the reference prints every sequence as soon as it exists (pgen_msa_revised.py:107-115, flush=True).  The
+    batched pipeline appends and flushes after every chunk of `template_batch` jobs, in the reference's order."""
+    s = _RecordingSampler()
+    o = _run_pgen_msa_revised(tmp_path, monkeypatch, s)
+    assert [c[0] for c in s.calls] == [4, 4, 2] and all(c[1] == -1 and c[2] == 4 for c in s.calls)
+    names = [ln[1:] for ln in o.read_text().splitlines() if ln.startswith(">")]
+    assert names == ["%d_t%d" % (i, t) for t in range(5) for i in range(2)]
+
+
+def test_pgen_msa_revised_keeps_finished_chunks_when_a_late_one_fails(tmp_path, monkeypatch):
+    s = _RecordingSampler(fail_on_call=2)
+    with pytest.raises(RuntimeError):
+        _run_pgen_msa_revised(tmp_path, monkeypatch, s)
+    names = [ln[1:] for ln in (tmp_path / "o.fasta").read_text().splitlines() if ln.startswith(">")]
+    assert names == ["%d_t%d" % (i, t) for t in range(4) for i in range(2)]      # two chunks of four were flushed
+
+
+def test_pgen_msa_revised_every_rank_writes_unless_one_job_is_sharded(monkeypatch):
+    """a process group that merely exists must not silence ranks > 0 (each runs its OWN job by default)."""
+    from protein_gibbs_sampler_amd import sharding
+
+    class Ctx:
+        rank, world = 1, 2
+    monkeypatch.setattr(sharding, "dist_context", lambda: Ctx())
+    s = _RecordingSampler()
+    assert pgen_msa_revised._writes_output(s)                     # rank 1, sharding off -> writes its own file
+    s.shard_over_ranks = True
+    assert not pgen_msa_revised._writes_output(s)                 # rank 1 of a sharded job -> rank 0 writes
+    Ctx.rank = 0
+    assert pgen_msa_revised._writes_output(s)
