@@ -26,9 +26,15 @@ struct DeviceGuard {
   }
 };
 
-int check_params(const pg_sample_params* p) {
+// vocab > 0: also that every valid_idx entry indexes a logit row of that width.  The engine entry points pass the model's
+// vocabulary: a replayed hipGraph copies the parameters into its device-side state block without going through
+// launch_sample_writeback's own host-side check.
+int check_params(const pg_sample_params* p, int vocab = 0) {
   if (!p) return fail(PG_ERR_INVALID, "null pg_sample_params");
   if (p->n_valid < 1 || p->n_valid > 32) return fail(PG_ERR_INVALID, "n_valid must be in 1..32");
+  if (vocab > 0)
+    for (int j = 0; j < p->n_valid; ++j)
+      if (p->valid_idx[j] < 0 || p->valid_idx[j] >= vocab) return fail(PG_ERR_INVALID, "sample: valid_idx out of range");
   return PG_OK;
 }
 
@@ -138,7 +144,7 @@ int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T,
                             int P, const pg_sample_params* params, float* d_sampled_logits, int32_t* d_sampled_tokens) {
   if (!h || !d_tokens_inout || (!d_target_idx && P > 0 && n_iters > 0))
     return fail(PG_ERR_INVALID, "pg_esm_gibbs_run_device: null argument");
-  int rc = check_params(params);
+  int rc = check_params(params, h->e.cfg.vocab);
   if (rc) return rc;
   DeviceGuard g(h->e.device);
   return h->e.esm_gibbs_device(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
@@ -147,7 +153,7 @@ int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T,
 int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,
                      const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
   if (!h || !tokens_inout || (!target_idx && P > 0 && n_iters > 0)) return fail(PG_ERR_INVALID, "pg_esm_gibbs_run: null argument");
-  int rc = check_params(params);
+  int rc = check_params(params, h->e.cfg.vocab);
   if (rc) return rc;
   if (B < 0 || T < 1 || P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "bad shape");
   if (B == 0) return PG_OK;
@@ -201,7 +207,7 @@ int pg_msa_forward_logits(pg_engine* h, const int32_t* tokens, int B, int R, int
 int pg_msa_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int R, int C, const int32_t* target_idx, int n_iters,
                      int P, const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
   if (!h || !tokens_inout || (!target_idx && P > 0 && n_iters > 0)) return fail(PG_ERR_INVALID, "pg_msa_gibbs_run: null argument");
-  int rc = check_params(params);
+  int rc = check_params(params, h->e.cfg.vocab);
   if (rc) return rc;
   if (B < 0 || R < 1 || C < 1 || P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "bad shape");
   if (B == 0) return PG_OK;
@@ -239,9 +245,39 @@ int pg_msa_gibbs_single_batch_run(pg_engine* h, int32_t* tokens_inout, int B, in
   int rc;
   if (!params) return fail(PG_ERR_INVALID, "null pg_sample_params");
   for (int b = 0; b < B; ++b)
-    if ((rc = check_params(params + b))) return rc;
+    if ((rc = check_params(params + b, h->e.cfg.vocab))) return rc;
   Engine& e = h->e;
   DeviceGuard g(e.device);
+  {
+    // The tied row attention of a template batch runs in its split-R form (every template as if alone), whose
+    // fp32 scratch grows with B: 0.5 GB for 4 templates of 128 x 513, past 2 GB from about B = 9 at C = 576 or B = 32 at C = 300.
+    // Templates are independent, so a larger batch is simply run in chunks that fit (same logits and tokens; ADVICE r03:
+    // `--template_batch 32`, BASELINE config 5's "32 templates", used to fail with PG_ERR_INVALID).
+    static const size_t limit = [] { const char* ev = getenv("PGIBBS_SPLIT_SCRATCH_MB"); return (size_t)(ev ? atol(ev) : 1024) << 20; }();
+    const size_t need1 = msa_row_split_scratch_bytes(1, R, C, e.cfg.n_heads, e.cfg.n_heads);
+    const int bc = need1 ? (int)std::max<size_t>(1, std::min<size_t>((size_t)B, limit / need1)) : B;
+    if (bc < B) {
+      std::vector<int32_t> idx_c, tok_c;
+      std::vector<float> lg_c;
+      const int V = e.cfg.vocab;
+      for (int b0 = 0; b0 < B; b0 += bc) {
+        const int nb = std::min(bc, B - b0);
+        idx_c.assign((size_t)n_steps * nb * P_max + 1, -1);
+        for (int s2 = 0; s2 < n_steps && P_max > 0; ++s2)
+          memcpy(idx_c.data() + (size_t)s2 * nb * P_max, step_idx + ((size_t)s2 * B + b0) * P_max, (size_t)nb * P_max * 4);
+        if (sampled_logits) lg_c.assign((size_t)n_steps * nb * P_max * V + 1, 0.f);
+        if (sampled_tokens) tok_c.assign((size_t)n_steps * nb * P_max + 1, 0);
+        if ((rc = pg_msa_gibbs_single_batch_run(h, tokens_inout + (size_t)b0 * R * C, nb, R, C, mask_row, target_row, idx_c.data(),
+                                                step_sample_flag, n_steps, P_max, params + b0, sampled_logits ? lg_c.data() : nullptr,
+                                                sampled_tokens ? tok_c.data() : nullptr))) return rc;
+        for (int s2 = 0; s2 < n_steps && P_max > 0; ++s2) {
+          if (sampled_logits) memcpy(sampled_logits + ((size_t)s2 * B + b0) * P_max * V, lg_c.data() + (size_t)s2 * nb * P_max * V, (size_t)nb * P_max * V * 4);
+          if (sampled_tokens) memcpy(sampled_tokens + ((size_t)s2 * B + b0) * P_max, tok_c.data() + (size_t)s2 * nb * P_max, (size_t)nb * P_max * 4);
+        }
+      }
+      return PG_OK;
+    }
+  }
   const size_t tok_bytes = (size_t)B * R * C * 4;
   const size_t n_draws = (size_t)B * P_max * n_steps;
   if (n_draws && (rc = check_idx_table(step_idx, n_draws, C, "pg_msa_gibbs_single_batch_run"))) return rc;
@@ -279,7 +315,7 @@ int pg_msa_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int R,
                             int32_t* d_sampled_tokens) {
   if (!h || !d_tokens_inout || (!d_target_idx && P > 0 && n_iters > 0))
     return fail(PG_ERR_INVALID, "pg_msa_gibbs_run_device: null argument");
-  int rc = check_params(params);
+  int rc = check_params(params, h->e.cfg.vocab);
   if (rc) return rc;
   DeviceGuard g(h->e.device);
   return h->e.msa_gibbs_device(d_tokens_inout, B, R, C, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
@@ -357,7 +393,7 @@ int pg_sample_writeback_device(void* stream, int32_t* d_tokens, int64_t n_rows, 
                                const int32_t* d_idx, const int32_t* d_row_map, int64_t n_sel, int P,
                                const pg_sample_params* params, int iteration, int32_t* d_sampled_tokens) {
   if (!d_tokens || !d_logits || (!d_idx && n_sel * P > 0)) return fail(PG_ERR_INVALID, "pg_sample_writeback_device: null argument");
-  int rc = check_params(params);
+  int rc = check_params(params, V);
   if (rc) return rc;
   if (n_rows < 0 || width < 1 || n_sel < 0 || P < 0 || V < 1) return fail(PG_ERR_INVALID, "bad shape");
   return launch_sample_writeback((hipStream_t)stream, d_tokens, width, d_logits, V, 0, d_idx, d_row_map, n_sel, P, params,

@@ -572,8 +572,10 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       // order of the sum over alignment rows, and a shard must compute what the whole batch would)
       const size_t need = msa_row_split_scratch_bytes(B, R, C, H, (int)(job_batch(B) * H));
       if (need) {
-        if (need <= ((size_t)1 << 31) && !(rc = scores.ensure(need, stream))) part = scores.as<float>();
-        else return fail(PG_ERR_INVALID, "too many MSAs in one call for the row-split attention scratch: use smaller batches");
+        // the host entry points chunk a batch of templates so that this fits (api.hip); a device-pointer caller gets the reason
+        if (need > ((size_t)1 << 31)) return fail(PG_ERR_INVALID, "too many MSAs in one call for the row-split attention scratch: use smaller batches");
+        if ((rc = scores.ensure(need, stream))) return rc;           // the allocator's own error (out of memory)
+        part = scores.as<float>();
       }
       if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0, (int)(job_batch(B) * H)); }))) return rc;
     } else {

@@ -29,10 +29,6 @@
 
 namespace pg {
 
-#ifndef PG_RESID_R2_DEFAULT
-#define PG_RESID_R2_DEFAULT 0
-#endif
-
 // Stage ROWS x 64 bf16 (128 B per row) into LDS.  One wave-instruction = 8 rows = 1 KiB, written
 // lane-linearly; lane l covers row (l>>3), LDS chunk (l&7), which receives global chunk (l&7)^(row&7).
 template <int ROWS, int NW>
@@ -326,7 +322,7 @@ template <int EPI, int ABL = 0, int GM = 4>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
                                                           int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
-                                                          int tail_m0, int stagger) {
+                                                          int tail_m0) {
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
@@ -349,12 +345,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   const int wm = grp, wn = wave & 3;              // wave tile: rows wm*128.. of X, rows wn*64.. of W
 
   int bid = n_tail > 0 ? blockIdx.x - n_tail : blockIdx.x;
-  // experiment (PGIBBS_PP_STAGGER = shader cycles): every other CU of each XCD starts its first tile late, so that within an XCD
-  // half of the CUs run main loops while the other half are in their read-modify-write epilogues
-  if (ABL == 0 && stagger > 0 && bid < 256 && ((bid >> 3) & 1)) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < (unsigned long long)stagger) __builtin_amdgcn_s_sleep(32);
-  }
   if (ABL == 18 && (bid & 7) != 0) return;        // timing experiment: only the workgroups of XCD 0 run (1/8 of the tiles)
   if (ABL == 19 && (bid & 7) > 1) return;         // ... XCDs 0 and 1
   {
@@ -507,10 +497,8 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   static const int tail_last = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_LAST"); return e ? atoi(e) : 0; }();
   const int n_tail_abs = (tail_rows / 64) * (N / 64), tail_m0 = M;
   const int n_tail = tail_last ? -n_tail_abs : n_tail_abs;
-  static const int stagger_env = [] { const char* e = getenv("PGIBBS_PP_STAGGER"); return e ? atoi(e) : 0; }();
-  const int stagger = epi == EPI_F32_RESID ? stagger_env : 0;
   dim3 grid(n_tiles + n_tail_abs), block(512);
-#define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, stagger
+#define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0
   if (abl) {   // ablations: EPI_BF16 only
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, PG_PP_ARGS);
     if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, PG_PP_ARGS);
@@ -563,18 +551,16 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 
 // geometry of a big-batch launch: m-panels of 256 x 256 tiles + rows of 64 x 64 tail tiles (launch_gemm_big)
 struct BigGeom { int m_main, tail_rows, gm; };
-// tile_n x 256-row tiles, `slots` resident workgroups per CU (256 x 256: one; the two-resident residual kernel's 256 x 128: two)
-static BigGeom big_geometry(int M, int N, int K, int tile_n = 256, int slots = 1) {
+static BigGeom big_geometry(int M, int N, int K) {
   static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
   static const int tail_on = [] { const char* e = getenv("PGIBBS_GEMM_TAIL"); return e ? atoi(e) : 1; }();
   static const int tail_max = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_MAX"); return e ? atoi(e) : 4; }();   // tail tiles per CU at most
   static const int gm_env = [] { const char* e = getenv("PGIBBS_GEMM_GM"); return e ? atoi(e) : 0; }();
-  const int tiles_n = N / tile_n, tiles_m = M / 256;
-  const long n_slot = (long)n_cu * slots;
-  const long t256 = (long)tiles_m * tiles_n, full = t256 / n_slot, frac = t256 - full * n_slot;
+  const int tiles_n = N / 256, tiles_m = M / 256;
+  const long t256 = (long)tiles_m * tiles_n, full = t256 / n_cu, frac = t256 - full * n_cu;
   BigGeom g{tiles_m, 0, gm_env ? (gm_env <= 2 ? gm_env : 4) : (K >= 4096 ? 2 : 4)};      // the GM the launchers instantiate
   if (tail_on && frac > 0) {
-    const int mm = (int)(full * n_slot / tiles_n);           // m-panels that fill whole rounds (0: less than one round of big tiles)
+    const int mm = (int)(full * n_cu / tiles_n);             // m-panels that fill whole rounds (0: less than one round of big tiles)
     const long n_tail = (long)(tiles_m - mm) * 4 * (N / 64);
     if (n_tail <= (long)tail_max * n_cu) { g.m_main = mm; g.tail_rows = (tiles_m - mm) * 256; }
   }
@@ -594,13 +580,6 @@ int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
                     int ldw, int ldo, int epi) {
   if (M % 256 || N % 256 || K % 64 || K < 128 || M < 256) return fail(1, "gemm_big: shape");
   static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? 16 : 0); }();
-  // residual updates: the two-resident 256 x 128 kernel (gemm_r2.hip), whose read-modify-write epilogue overlaps the other
-  // resident's main loop; PGIBBS_GEMM_RESID=pp keeps the 8-wave 256 x 256 kernel
-  static const int resid_r2 = [] { const char* e = getenv("PGIBBS_GEMM_RESID"); return e ? (e[0] == 'r') : PG_RESID_R2_DEFAULT; }();
-  if (epi == EPI_F32_RESID && resid_r2 && big == -1) {
-    const BigGeom g2 = big_geometry(M, N, K, 128, 2);
-    return launch_gemm_r2(s, X, W, bias, (float*)out, g2.m_main * 256, N, K, ldx, ldw, ldo, 0, g2.tail_rows);
-  }
   const BigGeom geo = big_geometry(M, N, K);
   const int m_main = geo.m_main, tail_rows = geo.tail_rows;
   const bool bf16out = epi == EPI_BF16 || epi == EPI_BF16_GELU;
@@ -1021,10 +1000,6 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   if (M % 128 || N % 64) return fail(1, "gemm: M must be a multiple of 128 and N of 64");
   const bool ok256 = M % 256 == 0 && N % 256 == 0 && K >= 128, ok128 = N % 128 == 0;
   const long t256 = (long)(M / 256) * (N / 256), t128 = (long)(M / 128) * (N / 128);
-  if (variant >= 50 && variant < 60 && ok256 && epi == EPI_F32_RESID) {     // the two-resident residual kernel; 54 / 53: its ablations
-    if (variant == 50) { const BigGeom g2 = big_geometry(M, N, K, 128, 2); return launch_gemm_r2(s, X, W, bias, (float*)out, g2.m_main * 256, N, K, ldx, ldw, ldo, 0, g2.tail_rows); }
-    return launch_gemm_r2(s, X, W, bias, (float*)out, M, N, K, ldx, ldw, ldo, variant == 54 ? 4 : 13, 0);
-  }
   if (variant >= 80 && ok256) return launch_gemm_w16(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 80);
   if (variant >= 60 && ok256) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 40);   // pp ablations 20..
   if (variant >= 20 && ok256) return launch_pp(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant - 20);

@@ -76,12 +76,12 @@ template <int EPI> struct EpiTraits {
 // SPLIT3 (strict precision mode, gemm_w16.hip): operands in the split layout, K = logical depth; a K-step is one group of 32
 // columns -- 128 B per row: xl | xh, wh | wl -- at a source stride of 192 B, and three products per step in the fused kernel's
 // order (wh.xl, wl.xh, wh.xh).
-template <int NW, int EPI, bool SPLIT3 = false, int STAGES = 8>
+template <int NW, int EPI, bool SPLIT3 = false>
 __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                  const float* __restrict__ bias, void* __restrict__ out, int K, int ldx, int ldw,
                                                  int ldo, int m0, int n0, char* smem) {
   static_assert(NW == 8 || NW == 16, "tail tile: 8 or 16 waves");
-  constexpr int STAGE_BYTES = 16384, PPW = 16 / NW, TM = 16 / NW;       // STAGES: a power of two (8: the 128-KB kernels; 4: 64 KB)
+  constexpr int STAGES = 8, STAGE_BYTES = 16384, PPW = 16 / NW, TM = 16 / NW;
   typedef EpiTraits<EPI> T;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

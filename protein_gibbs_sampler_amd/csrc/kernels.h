@@ -39,10 +39,6 @@ void gemm_big_geometry(int M, int N, int K, int* m_main_panels, int* tail_rows);
 // tail_rows rows of 64 x 64 tail tiles from row M on
 int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
                     int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0);
-// the two-resident residual kernel (gemm_r2.hip): out[M + tail_rows][N] += X W^T + bias as 256 x 128 tiles (8 waves, 72 KB of LDS:
-// two workgroups per CU) + 64 x 64 tail tiles; M a multiple of 256 (may be 0), N of 128, K of 32
-int launch_gemm_r2(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, float* out, int M, int N, int K, int ldx,
-                   int ldw, int ldo, int abl = 0, int tail_rows = 0);
 // strict mode: the three split-bf16 products of a projection in one pass (gemm_w16.hip); X3 / W3 in the split operand layout,
 // K = logical depth; bit-identical with launch_gemm_bf16 over K' = 3K on the same operands
 int launch_gemm_split3(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K, int ldo,

@@ -148,6 +148,54 @@ def test_config5_four_templates_per_call_equal_four_serial_calls(msa_model):
     assert len(set(serial)) == 4
 
 
+_DEFAULT_SHAPE_CHILD = r"""
+import random, sys, warnings, numpy as np, torch
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import esm_msa_sampler, models, weights
+cfg = dict(weights.MSA1B_CONFIG)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    m = models.ESM_MSA1(state_dict=weights.synthetic_state_dict(cfg, seed=2, std=0.025, embed_std=0.3, ln_jitter=0.1), config=cfg)
+def template(R, L, seed):
+    rng = np.random.default_rng(seed)
+    rows = np.asarray(list("ACDEFGHIKLMNPQRSTVWY"))[rng.integers(0, 20, (R, L))]
+    rows[rng.random((R, L)) < 0.1] = "-"
+    return ["".join(r) for r in rows]
+s = esm_msa_sampler.ESM_MSA_sampler(m, device="cuda:0")
+s.record = True
+msas = [template(32, 299, 300 + i) for i in range(4)]
+random.seed(9); torch.manual_seed(3)
+out = s.generate_single_batch([list(x) for x in msas], steps=1, passes=2, burn_in=1, target_index=0, k=1, max_batch=int(sys.argv[1]))
+np.savez(sys.argv[2], strings=np.asarray(out), logits=np.stack([r["sampled_logits"] for r in s.last_run]),
+         tokens=np.stack([r["sampled_tokens"] for r in s.last_run]), final=np.stack([r["tokens"] for r in s.last_run]))
+"""
+
+
+def test_default_pgen_msa_shape_batched_chunked_and_serial_agree(tmp_path):
+    """the default pgen_msa_revised shape (alignment_size 32 x ~300 columns: 9.6 k token rows per template) sends the
+    N = 768 projections of ONE template to the 64^2 / 128^2 kernels and those of FOUR to the 256^2 + tail-tile launch; identity
+    rests on every tile kernel walking k in the same order.  steps = 1 makes every step draw 299 positions (> 256 draws per
+    call).  Three child processes: one template per call, four per call, and four per call with the split-R scratch limit at
+    1 MB, which forces pg_msa_gibbs_single_batch_run to chunk the batch -- logits, tokens and strings must agree bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, mb, env_extra in (("serial", 1, {}), ("batched", 4, {}), ("chunked", 4, {"PGIBBS_SPLIT_SCRATCH_MB": "1"})):
+        out = tmp_path / (tag + ".npz")
+        p = subprocess.run([sys.executable, "-c", _DEFAULT_SHAPE_CHILD % root, str(mb), str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, **env_extra), timeout=1200)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        res[tag] = np.load(out)
+    assert res["serial"]["logits"].shape[1:3] == (2, 299)          # 2 steps (passes) x 299 draws each
+    for tag in ("batched", "chunked"):
+        assert list(res[tag]["strings"]) == list(res["serial"]["strings"])
+        assert np.array_equal(res[tag]["logits"].view(np.uint32), res["serial"]["logits"].view(np.uint32))
+        assert (res[tag]["tokens"] == res["serial"]["tokens"]).all() and (res[tag]["final"] == res["serial"]["final"]).all()
+    assert len(set(res["serial"]["strings"])) == 4
+
+
 # ---- the reference's plug-in protocol ------------------------------------------------------------------------------
 def test_native_model_call_protocol_esm():
     """`self.model.model(batch)["logits"]` exactly as /root/reference/src/pgen/esm_sampler.py:223 issues it: an int64 torch

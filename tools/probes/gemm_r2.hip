@@ -1,3 +1,12 @@
+// PROBE, not part of libpgibbs.so (round 4, VERDICT r03 item 1a: built, measured, lost; numbers in
+// profiles/r04_two_resident_gemm_and_stagger.txt, analysis in DESIGN.md section 4 "Round 4").  Bit-identical with the 8-wave
+// 256 x 256 kernel at 7 shapes, and its read-modify-write epilogue does hide under the other resident's main loop (fc2: 12 us of
+// it visible) -- but a 256 x 128 tile needs 1.5 x the L2 -> LDS bytes per FLOP of a 256 x 256 tile and its main loop runs at
+// 870-1000 TFLOP/s instead of 1240: out-projection 279 vs 260 us, fc2 1004 vs 767 us, config-2 iteration 96.3 vs 87.9 ms.  Two
+// resident 256 x 256 tiles do not fit the register file (2 x 256 KB of accumulators = all of it).
+// To try it again: copy next to csrc/gemm_w16.hip, add it to the Makefile, declare launch_gemm_r2 in kernels.h, give
+// gemm_tail_tile64 a STAGES template parameter (4 stages = 64 KB) and route EPI_F32_RESID to it in launch_gemm_big with
+// big_geometry(M, N, K, tile_n = 128, slots = 2) (git show HEAD~1 has the wiring).
 // Residual-update GEMM with TWO resident workgroups per CU:   x[M][N] += A[M][K] . W[N][K]^T + bias[N]   (fp32 accumulate)
 //
 // The attention out-projection and fc2 of every layer behind `self.model.model(batch)` (/root/reference/src/pgen/esm_sampler.py:223;
