@@ -53,8 +53,10 @@ def parse_args(argv=None):
     ap.add_argument("--weak", action="store_true", help="weak scaling: 256 chains PER GPU instead of 256 in total")
     ap.add_argument("--chains", type=int, default=TOTAL_CHAINS, help="chains in total (per GPU with --weak)")
     ap.add_argument("--length", type=int, default=256)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
-                    help="mode of the timed run: bf16 = throughput mode (the headline), fp32 = strict parity mode")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="mode of the timed run: bf16 = throughput mode (the headline), fp16 = the same kernels with fp16 operands, "
+                         "fp32 = strict parity mode")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-operand leg (N = 1)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the JSON then says so)")
     ap.add_argument("--greedy-after-burnin", action="store_true",
                     help="SURVEY 8d variant: top_k=1, burnin=25 (argmax after 25 sampled iterations) instead of all-sampling")
@@ -113,7 +115,7 @@ def measured_gemm_traffic():
     return 1e6 * sum(n * mb for n, mb in gem) / sum(n for n, _ in gem), os.path.basename(paths[-1])
 
 
-def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, target_seconds=12.0):
+def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, target_seconds=12.0, lm_f16=None):
     """The CPU oracle (checker, never the product) timed on a bounded sample of the same workload -- b chains x one full
     Gibbs iteration (mask, fp32 forward, draw), linear in chains -- and used as the checker of the engines' logits on those
     very chains.  Plus BASELINE.md section 3's two other asks: config 1 in full and the reference-style per-position loop."""
@@ -153,12 +155,24 @@ def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, target_se
     # the oracle as checker: logits of both engine modes at the sampled rows of those b chains
     cfg2_logits = keep["logits"]
     check = {"chains": b, "rows": int(b * P), "logit_std": float(keep["logits"].std())}
-    for name, eng in (("bf16", lm), ("fp32", lm_strict)):
+    def dist20(lg):                                   # the distribution generate_step samples from: softmax over the valid residues
+        z = lg[:, valid_idx].astype(np.float64)
+        z = np.exp(z - z.max(axis=1, keepdims=True))
+        return z / z.sum(axis=1, keepdims=True)
+    p_ref = dist20(keep["logits"])
+    for name, eng in (("bf16", lm), ("fp16", lm_f16), ("fp32", lm_strict)):
         if eng is None:
             continue
         full = eng.forward_logits(keep["masked"])
         got = np.stack([full[i, keep["idx"][i]] for i in range(b)]).reshape(b * P, -1)
-        check[name + "_max_abs_logit_err"] = float(np.abs(got - keep["logits"]).max())
+        err = np.abs(got - keep["logits"])
+        check[name + "_max_abs_logit_err"] = float(err.max())
+        check[name + "_mean_abs_logit_err"] = float(err.mean())
+        q = dist20(got)
+        kl = (q * (np.log(q + 1e-300) - np.log(p_ref + 1e-300))).sum(axis=1)
+        check[name + "_argmax_agreement"] = float((got[:, valid_idx].argmax(1) == keep["logits"][:, valid_idx].argmax(1)).mean())
+        check[name + "_kl_sampled_dist_mean"] = float(kl.mean())
+        check[name + "_kl_sampled_dist_max"] = float(kl.max())
     out["logit_check"] = check
 
     # BASELINE config 1 in full on the CPU: one chain, L = 25, P = 2, 20 iterations (top_k = 1, burnin = 10)
@@ -314,7 +328,7 @@ def main():
     if not dry:
         assert ((final[:, 1:-1] >= 4) & (final[:, 1:-1] <= 23)).all(), "chains left the 20-amino-acid alphabet"
 
-    mode = "bf16" if args.precision == "bf16" else "bf16x3"
+    mode = {"bf16": "bf16", "fp16": "fp16", "fp32": "bf16x3"}[args.precision]
     out = {"metric": "sampled positions/sec (whole node), ESM-1b L=256 B=256 Gibbs", "value": B_total * P * K / elapsed,
            "unit": "sampled positions/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": mode,
@@ -324,7 +338,7 @@ def main():
                                   "synthetic weights N(0,0.025), embeddings N(0,0.3), LayerNorm jitter 0.1 (logit std ~10)"
                                   % (B_total, "/".join(str(c) for c in sorted(set(counts))), L, T, P, top_k,
                                      "inf" if burnin == float("inf") else int(burnin),
-                                     "bf16 MFMA operands, fp32 accumulate + fp32 residual stream" if args.precision == "bf16"
+                                     "%s MFMA operands, fp32 accumulate + fp32 residual stream" % args.precision if args.precision != "fp32"
                                      else "strict mode: split-bf16 x3 MFMA GEMMs and attention products, fp32 softmax/LayerNorm/residual"),
                       "global_batch": B_total, "seq_len": L,
                       "parallelism": "chains sharded %d-way (contiguous blocks), 1 %s all-gather at the end"
@@ -411,6 +425,25 @@ def main():
         out["strict_mode"] = {"value": B_total * P * ks / ts, "unit": "sampled positions/s", "ms_per_step": 1e3 * ts / ks, "steps": ks,
                               "precision": "PG_PREC_FP32: split-bf16 x3 MFMA products (lo.hi + hi.lo + hi.hi) in the projections and in attention, fp32 accumulation/softmax/LayerNorm",
                               "max_abs_logit_err": None}
+    # fp16-operand throughput mode: the headline's kernels with v_mfma_f32_16x16x32_f16 and fp16 stores
+    lm_f16 = None
+    if rank == 0 and world == 1 and not dry and args.precision == "bf16" and not args.no_fp16:
+        lm_f16 = models.ESM1b(state_dict=sd, config=cfg, precision="fp16").model.to(str(dev))
+        _lib.check(L_.pg_engine_set_stream(lm_f16.handle, ctypes.c_void_p(stream.cuda_stream)))
+        lm_f16.set_job_items(B_total)
+        fj = Job(lm_f16, 0, B_total)
+        keep = fj.run(2)
+        torch.cuda.synchronize(dev)
+        kf = max(1, min(K, 10))
+        t0 = time.perf_counter()
+        keep = fj.run(kf)
+        torch.cuda.synchronize(dev)
+        tf = time.perf_counter() - t0
+        out["fp16_mode"] = {"value": B_total * P * kf / tf, "unit": "sampled positions/s", "ms_per_step": 1e3 * tf / kf, "steps": kf,
+                            "precision": "PG_PREC_F16: the bf16 mode's kernels with IEEE fp16 operands (v_mfma_f32_16x16x32_f16, fp16 "
+                                         "weights / LayerNorm outputs / q,k,v / softmax numerators / context / FFN rows), fp32 accumulation, "
+                                         "residual stream, softmax, LayerNorm",
+                            "max_abs_logit_err": None}
     gpu_cfg1 = None
     if rank == 0 and world == 1 and not dry and not args.no_cpu_baseline:
         # BASELINE config 1 on the GPU: one chain, L = 25 (T = 27), P = 2, 20 iterations, top_k = 1, burnin = 10
@@ -440,8 +473,12 @@ def main():
     if rank == 0 and world == 1 and not dry and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, lm if args.precision == "bf16" else None,
                                            lm_strict if lm_strict is not None else (lm if args.precision == "fp32" else None),
-                                           B_total, L, P, valid_idx, gpu_cfg1)
+                                           B_total, L, P, valid_idx, gpu_cfg1, lm_f16=lm_f16)
         chk = out["cpu_baseline"]["logit_check"]
+        if "fp16_mode" in out:
+            out["fp16_mode"].update({k_[5:]: v_ for k_, v_ in chk.items() if k_.startswith("fp16_")})
+            out["fp16_mode"]["logit_std"] = chk["logit_std"]
+            out["fp16_mode"]["bf16_mode_for_comparison"] = {k_[5:]: v_ for k_, v_ in chk.items() if k_.startswith("bf16_")}
         if "strict_mode" in out:
             out["strict_mode"]["max_abs_logit_err"] = chk.get("fp32_max_abs_logit_err")
             out["strict_mode"]["logit_std"] = chk["logit_std"]
@@ -449,7 +486,7 @@ def main():
     # ---- N = 1: the ESM-MSA-1b configurations (BASELINE configs 4 and 5) on the same GPU, driver-timed -------------------
     if rank == 0 and world == 1 and not dry and not args.no_msa and args.precision == "bf16":
         import bench_msa
-        del lm_strict
+        del lm_strict, lm_f16
         mw, mlm, mcfg = bench_msa.build("bf16", str(dev), realistic=True)
         _lib.check(L_.pg_engine_set_stream(mlm.handle, ctypes.c_void_p(stream.cuda_stream)))
         c4 = bench_msa.run_config4(mw, mlm, mcfg, steps=3, warmup=1, dev=dev)

@@ -74,6 +74,9 @@ typedef struct pg_engine pg_engine;
 #define PG_ARCH_MSA1B 2 /* fair-esm MSATransformer (esm_msa1b_t12_100M_UR50S) */
 
 #define PG_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream (throughput mode) */
+#define PG_PREC_F16 2  /* the throughput mode with IEEE fp16 operands instead of bf16 (same kernels, same MFMA rate; 3 more mantissa
+                          bits: logit error 8x smaller, profiles/r04_rounding_ablation.txt).  No saturation: a 16-bit tensor of the
+                          forward beyond +-65504 would become inf -- use PG_PREC_BF16 for such checkpoints. */
 #define PG_PREC_FP32 1 /* strict parity mode: every matrix product (projections, q.k^T, P.v) as three bf16 MFMA products on
                           (hi, lo) splits of both operands (lo.hi + hi.lo + hi.hi, fp32 accumulate); fp32 softmax, LayerNorm
                           and residual stream; ~3x slower, logits within 1e-3 of the fp32 oracle.  The FFN's GELU is
@@ -223,7 +226,8 @@ int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t*
 /* out[M][N] = x[M][K] @ w[N][K]^T + bias (fp32 host buffers; computed in `precision`); epi: 0 none, 1 gelu,
  * 2 residual (out is read too: out += x w^T + bias), 3 bf16 output, 4 bf16 output + gelu.  PG_PREC_FP32 (the engine's
  * strict-mode projection: one GEMM over K-concatenated split-bf16 operands) takes epi 0, 2 and 5 = fc1's fused epilogue
- * (GELU, then the split operand rows fc2 reads; N a multiple of 256; out = hi + lo of those rows) */
+ * (GELU, then the split operand rows fc2 reads; N a multiple of 256; out = hi + lo of those rows); PG_PREC_F16 = the bf16
+ * path's kernels with fp16 operands (epi 0-4) */
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi);
 /* times `iters` back-to-back launches of the GEMM on device-resident random bf16 operands (HIP events; M a multiple of 16,
@@ -234,11 +238,12 @@ int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int
 int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                      float eps);
 /* softmax(q k^T) v per (b, h); q already scaled; qkv[B][T][3*H*64] fp32 -> ctx[B][T][H*64]; PG_PREC_BF16 or PG_PREC_FP32
- * (split-bf16 MFMA kernel, output = hi + lo of the operand rows it writes) */
+ * (split-bf16 MFMA kernel, output = hi + lo of the operand rows it writes) or PG_PREC_F16 (the bf16 kernel with fp16 operands) */
 int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, int B, int T, int H);
 
 /* MSA attention blocks: qkv[B][R][C][3*H*64] fp32 -> ctx[B][R][C][H*64]; which = 0 tied row attention (scores * scale),
- * 1 column attention (q pre-scaled); 2 / 3 = the same two with the strict precision mode's kernels */
+ * 1 column attention (q pre-scaled); 2 / 3 = the same two with the strict precision mode's kernels; 4 / 5 = 0 / 1 with fp16
+ * operands */
 int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, int B, int R, int C, int H, float scale);
 
 #ifdef __cplusplus

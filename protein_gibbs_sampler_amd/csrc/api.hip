@@ -10,6 +10,8 @@
 #include "gemm_epilogue.h"
 
 namespace pg {
+// debug entries: operand flavour by the `precision` argument (fp16 operands for PG_PREC_F16, else bf16)
+#define DBG_OPS(fn, ...) (precision == PG_PREC_F16 ? opf16::fn(__VA_ARGS__) : opbf16::fn(__VA_ARGS__))
 const char* last_error_cstr();
 }
 using namespace pg;
@@ -475,7 +477,7 @@ int split3_rows_to_host(const bf16_t* c3, float* dst, int64_t M, int d) {
 
 int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const float* bias, float* out, int M, int N,
                 int K, int epi) {
-  if (precision != PG_PREC_BF16 && precision != PG_PREC_FP32) return fail(PG_ERR_INVALID, "unknown precision mode");
+  if (precision != PG_PREC_BF16 && precision != PG_PREC_FP32 && precision != PG_PREC_F16) return fail(PG_ERR_INVALID, "unknown precision mode");
   if (!x || !w || !bias || !out || M < 1 || N % 64 || K % 64) return fail(PG_ERR_INVALID, "pg_dbg_gemm: bad argument");
   DeviceGuard g(-1);
   int rc = dbg_device(device);
@@ -512,21 +514,21 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
     PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     return PG_OK;
   }
-  if ((rc = launch_f32_to_bf16(nullptr, dx, bx, (int64_t)Mp * K, 1.f))) return rc;
-  if ((rc = launch_f32_to_bf16(nullptr, dw, bw, (int64_t)N * K, 1.f))) return rc;
+  if ((rc = DBG_OPS(launch_f32_to_bf16, nullptr, dx, bx, (int64_t)Mp * K, 1.f))) return rc;
+  if ((rc = DBG_OPS(launch_f32_to_bf16, nullptr, dw, bw, (int64_t)N * K, 1.f))) return rc;
   if (epi == 2) PG_HIP(hipMemcpy(dout, out, (size_t)M * N * 4, hipMemcpyHostToDevice));     // residual variant: out += x w^T + b
   if (epi == 3 || epi == 4) {                       // bf16 outputs (the QKV / fc1 epilogues), widened to fp32 for the caller
     bf16_t* bout = (bf16_t*)t.get((size_t)Mp * N * 2);
     if (!bout) return fail(PG_ERR_HIP, "hipMalloc failed");
-    if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, bout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
-                               epi == 4 ? EPI_BF16_GELU : EPI_BF16))) return rc;
-    if ((rc = launch_bf16_to_f32(nullptr, bout, dout, (int64_t)M * N))) return rc;
+    if ((rc = DBG_OPS(launch_gemm_bf16, nullptr, bx, bw, db, bout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
+                      epi == 4 ? EPI_BF16_GELU : EPI_BF16, nullptr, 0))) return rc;
+    if ((rc = DBG_OPS(launch_bf16_to_f32, nullptr, bout, dout, (int64_t)M * N))) return rc;
   } else {
     // the residual variant gets split-K scratch, as the engine gives its fc2 GEMMs (taken for deep K and few tiles)
     const size_t ws_bytes = epi == 2 ? (size_t)5 * Mp * N * 4 : 0;
     float* ws = ws_bytes && ws_bytes <= ((size_t)1 << 30) ? (float*)t.get(ws_bytes) : nullptr;
-    if ((rc = launch_gemm_bf16(nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
-                               epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32), ws, ws ? ws_bytes : 0))) return rc;
+    if ((rc = DBG_OPS(launch_gemm_bf16, nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
+                      epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32), ws, ws ? ws_bytes : 0))) return rc;
   }
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -599,7 +601,7 @@ int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float
 }
 
 int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, int B, int T, int H) {
-  if (precision != PG_PREC_BF16 && precision != PG_PREC_FP32) return fail(PG_ERR_INVALID, "unknown precision mode");
+  if (precision != PG_PREC_BF16 && precision != PG_PREC_FP32 && precision != PG_PREC_F16) return fail(PG_ERR_INVALID, "unknown precision mode");
   if (!qkv || !ctx || B < 1 || T < 1 || H < 1) return fail(PG_ERR_INVALID, "pg_dbg_attention: bad argument");
   DeviceGuard g(-1);
   int rc = dbg_device(device);
@@ -621,9 +623,9 @@ int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, in
   float* dc = (float*)t.get((size_t)M * d * 4);
   if (!dq || !bq || !bc || !dc) return fail(PG_ERR_HIP, "hipMalloc failed");
   PG_HIP(hipMemcpy(dq, qkv, (size_t)M * 3 * d * 4, hipMemcpyHostToDevice));
-  if ((rc = launch_f32_to_bf16(nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
-  if ((rc = launch_attention_bf16(nullptr, bq, bc, B, T, H, 3 * d, d, d, 2 * d))) return rc;
-  if ((rc = launch_bf16_to_f32(nullptr, bc, dc, M * d))) return rc;
+  if ((rc = DBG_OPS(launch_f32_to_bf16, nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
+  if ((rc = DBG_OPS(launch_attention_bf16, nullptr, bq, bc, B, T, H, 3 * d, d, d, 2 * d, nullptr, -1))) return rc;
+  if ((rc = DBG_OPS(launch_bf16_to_f32, nullptr, bc, dc, M * d))) return rc;
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(ctx, dc, (size_t)M * d * 4, hipMemcpyDeviceToHost));
   return PG_OK;
@@ -633,6 +635,8 @@ int pg_dbg_attention(int device, int precision, const float* qkv, float* ctx, in
  * (scores scaled by `scale`), 1 = column attention (q already scaled); 2 / 3 = the same two in the strict precision mode */
 int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, int B, int R, int C, int H, float scale) {
   if (!qkv || !ctx || B < 1 || R < 1 || C < 1 || H < 1) return fail(PG_ERR_INVALID, "pg_dbg_msa_attention: bad argument");
+  const int precision = (which == 4 || which == 5) ? PG_PREC_F16 : PG_PREC_BF16;      // 4 / 5: which 0 / 1 with fp16 operands
+  if (which == 4 || which == 5) which -= 4;
   DeviceGuard g(-1);
   int rc = dbg_device(device);
   if (rc) return rc;
@@ -656,17 +660,17 @@ int pg_dbg_msa_attention(int device, int which, const float* qkv, float* ctx, in
   float* dc = (float*)t.get((size_t)M * d * 4);
   if (!dq || !bq || !bc || !dc) return fail(PG_ERR_HIP, "hipMalloc failed");
   PG_HIP(hipMemcpy(dq, qkv, (size_t)M * 3 * d * 4, hipMemcpyHostToDevice));
-  if ((rc = launch_f32_to_bf16(nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
+  if ((rc = DBG_OPS(launch_f32_to_bf16, nullptr, dq, bq, M * 3 * d, 1.f))) return rc;
   if (which == 0) {
     // scratch for the split-R mode (taken when B*H*ceil(C/64) < 384 and R >= 8), so the tests exercise both modes
     const size_t pbytes = (size_t)B * H * 16 * C * 576 * 4 + (size_t)B * H * (C / 16 + 9) * 18 * 1024;
     float* part = pbytes <= ((size_t)1 << 30) ? (float*)t.get(pbytes) : nullptr;
-    if ((rc = launch_msa_row_attention_bf16(nullptr, bq, bc, B, R, C, H, 3 * d, d, d, 2 * d, scale, part, part ? pbytes : 0))) return rc;
+    if ((rc = DBG_OPS(launch_msa_row_attention_bf16, nullptr, bq, bc, B, R, C, H, 3 * d, d, d, 2 * d, scale, part, part ? pbytes : 0, 0))) return rc;
   } else {
     SeqLayout col = {C, R * C, 1, C};
-    if ((rc = launch_attention_seq_bf16(nullptr, bq, bc, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col))) return rc;
+    if ((rc = DBG_OPS(launch_attention_seq_bf16, nullptr, bq, bc, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col, nullptr, -1))) return rc;
   }
-  if ((rc = launch_bf16_to_f32(nullptr, bc, dc, M * d))) return rc;
+  if ((rc = DBG_OPS(launch_bf16_to_f32, nullptr, bc, dc, M * d))) return rc;
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(ctx, dc, (size_t)M * d * 4, hipMemcpyDeviceToHost));
   return PG_OK;

@@ -18,7 +18,7 @@
 //   * O^T = V^T.P^T, so a lane ends with 4 consecutive d for one query -> 8-byte row-major stores.
 #include "kernels.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -137,10 +137,10 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         // producing its accumulator input (hipcc otherwise pairs them through one temporary register)
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-          st[ch * CH + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          st[ch * CH + u] = mfma_op16(kbuf[ch & 1][u][0], qf[0], (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-          st[ch * CH + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kbuf[ch & 1][u][1], qf[1], st[ch * CH + u], 0, 0, 0);
+          st[ch * CH + u] = mfma_op16(kbuf[ch & 1][u][1], qf[1], st[ch * CH + u]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -231,13 +231,13 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         if (c + 2 < nkc) load_v(c + 2, vbuf[(c + 2) % 3]);
         union { bf16x8 v; uint32_t u[4]; } pf;
         const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
-        pf.u[0] = pack_bf16x2(lo[0], lo[1]);
-        pf.u[1] = pack_bf16x2(lo[2], lo[3]);
-        pf.u[2] = pack_bf16x2(hi[0], hi[1]);
-        pf.u[3] = pack_bf16x2(hi[2], hi[3]);
+        pf.u[0] = pack_op2(lo[0], lo[1]);
+        pf.u[1] = pack_op2(lo[2], lo[3]);
+        pf.u[2] = pack_op2(hi[0], hi[1]);
+        pf.u[3] = pack_op2(hi[2], hi[3]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vbuf[c % 3][db].v, pf.v, o[db], 0, 0, 0);
+        for (int db = 0; db < 4; ++db) o[db] = mfma_op16(vbuf[c % 3][db].v, pf.v, o[db]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 p;
-        p.x = pack_bf16x2(o[db][0] * inv, o[db][1] * inv);
-        p.y = pack_bf16x2(o[db][2] * inv, o[db][3] * inv);
+        p.x = pack_op2(o[db][0] * inv, o[db][1] * inv);
+        p.y = pack_op2(o[db][2] * inv, o[db][3] * inv);
         *(uint2*)(dst + db * 16) = p;
       }
     }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+        st[kb] = mfma_op16(kf, qf[kk], st[kb]);
       }
     }
     float tmax = -3.0e38f;
@@ -379,10 +379,10 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
     for (int c = 0; c < nkc; ++c) {
       union { bf16x8 v; uint32_t u[4]; } pf;
       const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
-      pf.u[0] = pack_bf16x2(lo[0], lo[1]);
-      pf.u[1] = pack_bf16x2(lo[2], lo[3]);
-      pf.u[2] = pack_bf16x2(hi[0], hi[1]);
-      pf.u[3] = pack_bf16x2(hi[2], hi[3]);
+      pf.u[0] = pack_op2(lo[0], lo[1]);
+      pf.u[1] = pack_op2(lo[2], lo[3]);
+      pf.u[2] = pack_op2(hi[0], hi[1]);
+      pf.u[3] = pack_op2(hi[2], hi[3]);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         union { bf16x8 v; uint2 h2[2]; } vf;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
           vf.h2[hh] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
                                                     (__attribute__((address_space(3))) char*)a)));
         }
-        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[db], 0, 0, 0);
+        o[db] = mfma_op16(vf.v, pf.v, o[db]);
       }
     }
   }
@@ -405,8 +405,8 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       uint2 p;
-      p.x = pack_bf16x2(o[db][0] * inv, o[db][1] * inv);
-      p.y = pack_bf16x2(o[db][2] * inv, o[db][3] * inv);
+      p.x = pack_op2(o[db][0] * inv, o[db][1] * inv);
+      p.y = pack_op2(o[db][2] * inv, o[db][3] * inv);
       *(uint2*)(dst + db * 16) = p;
     }
   }
@@ -441,4 +441,4 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   return 0;
 }
 
-}  // namespace pg
+PG_OPS_END

@@ -14,7 +14,7 @@
 
 #include "kernels.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 // One thread's 64 context values of head h -> bf16 into the token's context row.  split_d > 0: the row is the strict mode's
 // split operand (3 * split_d values, groups of 32 columns [lo | hi | hi]; elementwise.hip store_row_bf16).
@@ -23,13 +23,13 @@ __device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf1
   for (int i = 0; i < 16; ++i) {
     const float a = o[4 * i] * inv, b = o[4 * i + 1] * inv, c = o[4 * i + 2] * inv, d = o[4 * i + 3] * inv;
     uint2 p, r;
-    p.x = pack_bf16x2(a, b);
-    p.y = pack_bf16x2(c, d);
+    p.x = pack_op2(a, b);
+    p.y = pack_op2(c, d);
     if (!split_d) {
       ((uint2*)(row + h * 64))[i] = p;
     } else {
-      r.x = pack_bf16x2(a - bf16_to_f32((bf16_t)(p.x & 0xffff)), b - bf16_to_f32((bf16_t)(p.x >> 16)));
-      r.y = pack_bf16x2(c - bf16_to_f32((bf16_t)(p.y & 0xffff)), d - bf16_to_f32((bf16_t)(p.y >> 16)));
+      r.x = pack_op2(a - op16_to_f32((bf16_t)(p.x & 0xffff)), b - op16_to_f32((bf16_t)(p.x >> 16)));
+      r.y = pack_op2(c - op16_to_f32((bf16_t)(p.y & 0xffff)), d - op16_to_f32((bf16_t)(p.y >> 16)));
       bf16_t* g = row + (2 * h + (i >> 3)) * 96 + (i & 7) * 4;       // columns h*64 + 4i .. +3
       *(uint2*)g = r;
       *(uint2*)(g + 32) = p;
@@ -44,11 +44,11 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 
 // 8 fp32 -> 8 bf16 hi (round to nearest even) + 8 bf16 lo = bf16(v - hi)
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
-  hi.x = pack_bf16x2(a.x, a.y); hi.y = pack_bf16x2(a.z, a.w); hi.z = pack_bf16x2(b.x, b.y); hi.w = pack_bf16x2(b.z, b.w);
-  lo.x = pack_bf16x2(a.x - __uint_as_float(hi.x << 16), a.y - __uint_as_float(hi.x & 0xffff0000u));
-  lo.y = pack_bf16x2(a.z - __uint_as_float(hi.y << 16), a.w - __uint_as_float(hi.y & 0xffff0000u));
-  lo.z = pack_bf16x2(b.x - __uint_as_float(hi.z << 16), b.y - __uint_as_float(hi.z & 0xffff0000u));
-  lo.w = pack_bf16x2(b.z - __uint_as_float(hi.w << 16), b.w - __uint_as_float(hi.w & 0xffff0000u));
+  hi.x = pack_op2(a.x, a.y); hi.y = pack_op2(a.z, a.w); hi.z = pack_op2(b.x, b.y); hi.w = pack_op2(b.z, b.w);
+  lo.x = pack_op2(a.x - __uint_as_float(hi.x << 16), a.y - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack_op2(a.z - __uint_as_float(hi.y << 16), a.w - __uint_as_float(hi.y & 0xffff0000u));
+  lo.z = pack_op2(b.x - __uint_as_float(hi.z << 16), b.y - __uint_as_float(hi.z & 0xffff0000u));
+  lo.w = pack_op2(b.z - __uint_as_float(hi.w << 16), b.w - __uint_as_float(hi.w & 0xffff0000u));
 }
 
 // Building blocks shared by the three split-bf16 MFMA kernels (full attention, tied-row scores, tied-row apply).
@@ -113,11 +113,11 @@ struct SplitAttn {
       for (int kk = 0; kk < 2; ++kk) {
         const int ad = krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4);
         kh[kk] = *(const bf16x8*)(Kh + ad);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Kl + ad), qh[kk], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kk], ql[kk], a, 0, 0, 0);
+        a = mfma_op16(*(const bf16x8*)(Kl + ad), qh[kk], a);
+        a = mfma_op16(kh[kk], ql[kk], a);
       }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh[kk], qh[kk], a, 0, 0, 0);
+      for (int kk = 0; kk < 2; ++kk) a = mfma_op16(kh[kk], qh[kk], a);
       st[kb] = a;
     }
   }
@@ -170,9 +170,9 @@ struct SplitAttn {
           vl.h2[hh] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
                                                     (__attribute__((address_space(3))) char*)(Vl + ad))));
         }
-        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl.v, pfh, o[db], 0, 0, 0);
-        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, pfl, o[db], 0, 0, 0);
-        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh.v, pfh, o[db], 0, 0, 0);
+        o[db] = mfma_op16(vl.v, pfh, o[db]);
+        o[db] = mfma_op16(vh.v, pfl, o[db]);
+        o[db] = mfma_op16(vh.v, pfh, o[db]);
       }
     }
   }
@@ -185,13 +185,13 @@ struct SplitAttn {
     for (int db = 0; db < 4; ++db) {
       const float a = o[db][0] * inv, b = o[db][1] * inv, c = o[db][2] * inv, d = o[db][3] * inv;
       uint2 p, r;
-      p.x = pack_bf16x2(a, b);
-      p.y = pack_bf16x2(c, d);
+      p.x = pack_op2(a, b);
+      p.y = pack_op2(c, d);
       if (!split_d) {
         *(uint2*)(row + h * 64 + db * 16 + fq * 4) = p;
       } else {
-        r.x = pack_bf16x2(a - __uint_as_float(p.x << 16), b - __uint_as_float(p.x & 0xffff0000u));
-        r.y = pack_bf16x2(c - __uint_as_float(p.y << 16), d - __uint_as_float(p.y & 0xffff0000u));
+        r.x = pack_op2(a - __uint_as_float(p.x << 16), b - __uint_as_float(p.x & 0xffff0000u));
+        r.y = pack_op2(c - __uint_as_float(p.y << 16), d - __uint_as_float(p.y & 0xffff0000u));
         bf16_t* g = row + (2 * h + (db >> 1)) * 96 + (db & 1) * 16 + fq * 4;
         *(uint2*)g = r;
         *(uint2*)(g + 32) = p;
@@ -578,4 +578,4 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
   return 0;
 }
 
-}  // namespace pg
+PG_OPS_END

@@ -13,7 +13,7 @@
 #include "kernels.h"
 #include "ln_row.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
@@ -270,10 +270,10 @@ __global__ void split3_bf16_kernel(const float* __restrict__ src, bf16_t* __rest
     v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
     if (GELU) { v.x = gelu_erf_exact(v.x); v.y = gelu_erf_exact(v.y); v.z = gelu_erf_exact(v.z); v.w = gelu_erf_exact(v.w); }
     uint2 p, q;
-    p.x = pack_bf16x2(v.x, v.y);
-    p.y = pack_bf16x2(v.z, v.w);
-    q.x = pack_bf16x2(v.x - bf16_to_f32((bf16_t)(p.x & 0xffff)), v.y - bf16_to_f32((bf16_t)(p.x >> 16)));
-    q.y = pack_bf16x2(v.z - bf16_to_f32((bf16_t)(p.y & 0xffff)), v.w - bf16_to_f32((bf16_t)(p.y >> 16)));
+    p.x = pack_op2(v.x, v.y);
+    p.y = pack_op2(v.z, v.w);
+    q.x = pack_op2(v.x - op16_to_f32((bf16_t)(p.x & 0xffff)), v.y - op16_to_f32((bf16_t)(p.x >> 16)));
+    q.y = pack_op2(v.z - op16_to_f32((bf16_t)(p.y & 0xffff)), v.w - op16_to_f32((bf16_t)(p.y >> 16)));
     const int64_t row = i / k4;
     const int ci = (int)(i - row * k4);
     uint2* o = (uint2*)dst + row * 3 * k4 + (ci >> 3) * 24 + (ci & 7);
@@ -292,12 +292,12 @@ __global__ void gelu_f32_kernel(float* __restrict__ p, int64_t n) {
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) dst[i] = f32_to_bf16_dev(src[i] * scale);
+  for (; i < n; i += stride) dst[i] = f32_to_op16_dev(src[i] * scale);
 }
 __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) dst[i] = bf16_to_f32(src[i]);
+  for (; i < n; i += stride) dst[i] = op16_to_f32(src[i]);
 }
 __global__ void scale_f32_kernel(float* __restrict__ p, int64_t n, float scale) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -415,4 +415,4 @@ int launch_scale_f32(hipStream_t s, float* p, int64_t n, float scale) {
   return 0;
 }
 
-}  // namespace pg
+PG_OPS_END

@@ -13,6 +13,10 @@
 
 namespace pg {
 
+// the operand-flavoured launchers (pg_common.h): fp16 operands in PG_PREC_F16, bf16 otherwise (the strict mode's split operands
+// are bf16 pairs)
+#define OPS(fn, ...) (precision == PG_PREC_F16 ? opf16::fn(__VA_ARGS__) : opbf16::fn(__VA_ARGS__))
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -138,7 +142,8 @@ struct Uploader {
         ok = ok && launch_split3_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * Kw, n_each, K, scales[p],
                                       false, true) == 0;
       else
-        ok = ok && launch_f32_to_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * K, (int64_t)n_each * K, scales[p]) == 0;
+        ok = ok && (e->precision == PG_PREC_F16 ? opf16::launch_f32_to_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * K, (int64_t)n_each * K, scales[p])
+                                              : opbf16::launch_f32_to_bf16(e->stream, (const float*)tmp, (bf16_t*)dw + (size_t)p * n_each * K, (int64_t)n_each * K, scales[p])) == 0;
       ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
       ok = ok && hipMemcpy((float*)db + (size_t)p * n_each, b, (size_t)n_each * 4, hipMemcpyHostToDevice) == hipSuccess;
       if (ok && scales[p] != 1.0f) ok = launch_scale_f32(e->stream, (float*)db + (size_t)p * n_each, n_each, scales[p]) == 0 &&
@@ -165,7 +170,7 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
   precision = prec;
   device = -1;
   if (cfg.arch != PG_ARCH_ESM1B && cfg.arch != PG_ARCH_MSA1B) return fail(PG_ERR_INVALID, "unknown arch");
-  if (prec != PG_PREC_BF16 && prec != PG_PREC_FP32) return fail(PG_ERR_INVALID, "unknown precision mode");
+  if (prec != PG_PREC_BF16 && prec != PG_PREC_FP32 && prec != PG_PREC_F16) return fail(PG_ERR_INVALID, "unknown precision mode");
   if (cfg.d_model % 128 || cfg.d_ffn % 128 || cfg.n_heads * 64 != cfg.d_model)
     return fail(PG_ERR_INVALID, "d_model and d_ffn must be multiples of 128 and head dim must be 64");
   if (cfg.vocab < 1 || cfg.vocab > 64) return fail(PG_ERR_INVALID, "vocab must be in 1..64");
@@ -284,18 +289,18 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     const float eps = cfg.layer_norm_eps;
     const int Mi = (int)Mp;
     rc = timed(PC_EMBED, [&] {
-      return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
+      return OPS(launch_embed_ln, stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
                              cfg.mask_idx, cfg.token_dropout, 0, eps);
     });
     if (rc) return rc;
     const SeqLayout chain = {1, T, 0, 1};
     for (int l = 0; l < cfg.n_layers; ++l) {
       const EsmLayer& L = esm_layers[l];
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
       if ((rc = dense3(h.as<bf16_t>(), L.qkv, QKVf, Mi, false))) return rc;
       if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), d, B, T, cfg.n_heads, 3 * d, 3 * d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
       if ((rc = dense3(ctx.as<bf16_t>(), L.out, X, Mi, true))) return rc;
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
       if ((rc = dense3_gelu(h.as<bf16_t>(), L.fc1, Mi))) return rc;
       if ((rc = dense3(ffn.as<bf16_t>(), L.fc2, X, Mi, true))) return rc;
     }
@@ -321,7 +326,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
 
   // embedding + emb_layer_norm_before, and in the same pass over the row the first layer's LayerNorm (its bf16 operand rows)
   rc = timed(PC_EMBED, [&] {
-    return launch_embed_ln(stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
+    return OPS(launch_embed_ln, stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
                            cfg.mask_idx, cfg.token_dropout, 0, eps, ln_in_gemm ? nullptr : esm_layers[0].ln1.g,
                            ln_in_gemm ? nullptr : esm_layers[0].ln1.b, ln_in_gemm ? nullptr : Hh);
   });
@@ -330,11 +335,11 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     const EsmLayer& L = esm_layers[l];
     // Hh holds LN1(x): written by the previous layer's fc2 launch (or the LayerNorm kernel) -- see resid_gemm_ln
     if (ln_in_gemm) {
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_ln_skinny(stream, X, d, L.ln1.g, L.ln1.b, eps, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, 3 * d, EPI_BF16); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_ln_skinny, stream, X, d, L.ln1.g, L.ln1.b, eps, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, 3 * d, EPI_BF16); }))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     }
-    if ((rc = timed(PC_ATTN, [&] { return launch_attention_bf16(stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_bf16, stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: only the selected rows are ever read again -> gather them and finish the layer on n_sel rows
       const int64_t Np = round_up64(n_sel, kRowPad);
@@ -348,28 +353,28 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
         return launch_gather_rows(stream, CTX, ctx_sel.as<bf16_t>(), sel_idx, nullptr, P, T, n_sel, d * 2, d_iter_);
       });
       if (rc) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.out.w, L.out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, ctx_sel.as<bf16_t>(), L.out.w, L.out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
       if (ln_in_gemm && gemm_ln_skinny_ok(Ni, f, d)) {
-        if ((rc = timed(PC_GEMM, [&] { return launch_gemm_ln_skinny(stream, XS, d, L.ln2.g, L.ln2.b, eps, L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, f, EPI_BF16_GELU); }))) return rc;
+        if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_ln_skinny, stream, XS, d, L.ln2.g, L.ln2.b, eps, L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, f, EPI_BF16_GELU); }))) return rc;
       } else {
-        if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln2.g, L.ln2.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
-        if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+        if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, XS, L.ln2.g, L.ln2.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
+        if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
       }
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
     }
     if (ln_in_gemm) {
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_ln_skinny(stream, X, d, L.ln2.g, L.ln2.b, eps, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, f, EPI_BF16_GELU); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_ln_skinny, stream, X, d, L.ln2.g, L.ln2.b, eps, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, f, EPI_BF16_GELU); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
       continue;
     }
     if ((rc = resid_gemm_ln(CTX, L.out, X, Mi, M, d, L.ln2, Hh))) return rc;                       // x += out_proj(ctx); h = LN2(x)
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
     if (l + 1 < cfg.n_layers) {                                                                    // x += fc2(ffn); h = LN1 of the next layer
       if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, esm_layers[l + 1].ln1, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
     }
   }
   return PG_OK;
@@ -381,9 +386,9 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
 int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
                           float* ws, size_t ws_bytes) {
   const int d = W.N, K = W.K;
-  int rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
+  int rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
   if (rc) return rc;
-  return timed(PC_LN, [&] { return launch_layernorm_bf16(stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps); });
+  return timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps); });
 }
 
 // LM head evaluated ONLY at the selected rows: emb_layer_norm_after -> dense -> GELU ->
@@ -399,17 +404,17 @@ int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int wid
   const float eps = cfg.layer_norm_eps;
   if (strict()) {
     if ((rc = sel_h.ensure((size_t)Np * 3 * d * 2, stream))) return rc;
-    if ((rc = launch_gather_ln_bf16(stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
+    if ((rc = OPS(launch_gather_ln_bf16, stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
                                     sel_h.as<bf16_t>(), n_sel, d, eps, true))) return rc;
     if ((rc = dense3(sel_h.as<bf16_t>(), head_dense, sel_g.as<float>(), (int)Np, false))) return rc;
     if ((rc = launch_gelu_f32(stream, sel_g.as<float>(), Np * d))) return rc;
     return launch_lm_tail(stream, sel_g.as<float>(), head_ln.g, head_ln.b, embed, head_bias, d_logits, n_sel, d, V, eps);
   }
   return timed(PC_HEAD, [&] {
-    int r = launch_gather_ln_bf16(stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
+    int r = OPS(launch_gather_ln_bf16, stream, x_src, d_idx_, d_row_map, P, width, ln_after.g, ln_after.b,
                                   sel_h.as<bf16_t>(), n_sel, d, eps);
     if (r) return r;
-    r = launch_gemm_bf16(stream, sel_h.as<bf16_t>(), head_dense.w, head_dense.b, sel_g.as<float>(),
+    r = OPS(launch_gemm_bf16, stream, sel_h.as<bf16_t>(), head_dense.w, head_dense.b, sel_g.as<float>(),
                          sel_gemm_rows(n_sel, Np), d, d, d, d, d, EPI_F32_GELU);
     if (r) return r;
     return launch_lm_tail(stream, sel_g.as<float>(), head_ln.g, head_ln.b, embed, head_bias, d_logits, n_sel, d, V, eps);
@@ -532,22 +537,22 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     const float eps2 = cfg.layer_norm_eps;
     const int Mi2 = (int)Mp;
     rc = timed(PC_EMBED, [&] {
-      return launch_embed_ln(stream, d_tok, embed, pos, msa_pos, ln_before.g, ln_before.b, Xs, M, C, d, cfg.pad_idx,
+      return OPS(launch_embed_ln, stream, d_tok, embed, pos, msa_pos, ln_before.g, ln_before.b, Xs, M, C, d, cfg.pad_idx,
                              cfg.mask_idx, 0, R, eps2);
     });
     if (rc) return rc;
     const SeqLayout colS = {C, R * C, 1, C};
     for (int l = 0; l < cfg.n_layers; ++l) {
       const MsaLayer& L = msa_layers[l];
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, Xs, L.ln_row.g, L.ln_row.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_row.g, L.ln_row.b, H3, M, d, eps2, true); }))) return rc;
       if ((rc = dense3(H3, L.row_qkv, QKVf, Mi2, false))) return rc;
       if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_f32(stream, QKVf, scores.as<float>(), C3, d, B, R, C, H, 3 * d, 3 * d, d, 2 * d, row_scale); }))) return rc;
       if ((rc = dense3(C3, L.row_out, Xs, Mi2, true))) return rc;
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, Xs, L.ln_col.g, L.ln_col.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_col.g, L.ln_col.b, H3, M, d, eps2, true); }))) return rc;
       if ((rc = dense3(H3, L.col_qkv, QKVf, Mi2, false))) return rc;
       if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, C3, d, (int64_t)B * C, R, H, 3 * d, 3 * d, d, 2 * d, colS); }))) return rc;
       if ((rc = dense3(C3, L.col_out, Xs, Mi2, true))) return rc;
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, Xs, L.ln_ffn.g, L.ln_ffn.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_ffn.g, L.ln_ffn.b, H3, M, d, eps2, true); }))) return rc;
       if ((rc = dense3_gelu(H3, L.fc1, Mi2))) return rc;
       if ((rc = dense3(ffn.as<bf16_t>(), L.fc2, Xs, Mi2, true))) return rc;
     }
@@ -556,7 +561,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
 
   // embedding + emb_layer_norm_before, and in the same pass over the row the first layer's row-attention LayerNorm
   rc = timed(PC_EMBED, [&] {
-    return launch_embed_ln(stream, d_tok, embed, pos, msa_pos, ln_before.g, ln_before.b, X, M, C, d, cfg.pad_idx,
+    return OPS(launch_embed_ln, stream, d_tok, embed, pos, msa_pos, ln_before.g, ln_before.b, X, M, C, d, cfg.pad_idx,
                            cfg.mask_idx, 0, R, eps, msa_layers[0].ln_row.g, msa_layers[0].ln_row.b, Hh);
   });
   if (rc) return rc;
@@ -565,7 +570,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   for (int l = 0; l < cfg.n_layers; ++l) {
     const MsaLayer& L = msa_layers[l];
     // tied row attention
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if (C <= 576) {
       float* part = nullptr;
       // few workgroups: give the kernel scratch for its split-R mode (decided on the job's batch: the split changes the
@@ -577,9 +582,12 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
         if ((rc = scores.ensure(need, stream))) return rc;           // the allocator's own error (out of memory)
         part = scores.as<float>();
       }
-      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_bf16(stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0, (int)(job_batch(B) * H)); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return OPS(launch_msa_row_attention_bf16, stream, QKV, CTX, B, R, C, H, 3 * d, d, d, 2 * d, row_scale, part, part ? scores.bytes : 0, (int)(job_batch(B) * H)); }))) return rc;
     } else {
       // alignments wider than the MFMA row-attention kernel's register budget: fp32 scores through a scratch buffer
+      if (precision == PG_PREC_F16)
+        return fail(PG_ERR_UNSUPPORTED, "fp16 precision mode: alignments wider than 576 columns take the split-bf16 row attention, "
+                                        "which exists for bf16 operands only -- use precision bf16 or fp32");
       if ((rc = scratch.ensure((size_t)Mp * 3 * d * 4, stream)) || (rc = scores.ensure((size_t)B * H * C * msa_row_scores_ld(C) * 4, stream))) return rc;
       rc = timed(PC_ATTN, [&] {
         int r2 = launch_bf16_to_f32(stream, QKV, scratch.as<float>(), (int64_t)M * 3 * d);
@@ -591,8 +599,8 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     }
     if ((rc = resid_gemm_ln(CTX, L.row_out, X, Mi, M, d, L.ln_col, Hh))) return rc;                 // x += row_out(ctx); h = LN_col(x)
     // column attention (q pre-scaled by dh^-0.5 in the weights)
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
-    if ((rc = timed(PC_ATTN, [&] { return launch_attention_seq_bf16(stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_seq_bf16, stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: nothing but the selected rows is read again -> finish column out-projection and FFN on n_sel rows
       const int64_t Np = round_up64(n_sel, kRowPad);
@@ -606,19 +614,19 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
         return launch_gather_rows(stream, CTX, ctx_sel.as<bf16_t>(), sel_idx, sel_row_map, P, C, n_sel, d * 2);
       });
       if (rc) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ctx_sel.as<bf16_t>(), L.col_out.w, L.col_out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
-      if ((rc = timed(PC_LN, [&] { return launch_layernorm_bf16(stream, XS, L.ln_ffn.g, L.ln_ffn.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, ctx_sel.as<bf16_t>(), L.col_out.w, L.col_out.b, XS, Ni, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, XS, L.ln_ffn.g, L.ln_ffn.b, h_sel.as<bf16_t>(), n_sel, d, eps); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, h_sel.as<bf16_t>(), L.fc1.w, L.fc1.b, ffn_sel.as<bf16_t>(), Ni, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
     }
     if ((rc = resid_gemm_ln(CTX, L.col_out, X, Mi, M, d, L.ln_ffn, Hh))) return rc;                 // x += col_out(ctx); h = LN_ffn(x)
     // feed forward
-    if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
     if (l + 1 < cfg.n_layers) {                                                                      // x += fc2(ffn); h = LN_row of the next layer
       if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, msa_layers[l + 1].ln_row, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM, [&] { return launch_gemm_bf16(stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
     }
   }
   return PG_OK;

@@ -27,7 +27,7 @@
 
 #include "gemm_epilogue.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 // Stage ROWS x 64 bf16 (128 B per row) into LDS.  One wave-instruction = 8 rows = 1 KiB, written
 // lane-linearly; lane l covers row (l>>3), LDS chunk (l&7), which receives global chunk (l&7)^(row&7).
@@ -107,7 +107,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_op16(wf[i], xf[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -127,8 +127,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_bf16_kernel(
       if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
         uint2 p;
         // every tile kernel sends the fc1 GELU through the same packed routine: rows stay bit-identical for any batch split
-        p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
-        p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
+        p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_op2(v0, v1);
+        p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_op2(v2, v3);
         *(uint2*)((bf16_t*)out + (size_t)m * ldo + n) = p;
       } else if (EPI == EPI_F32_RESID) {
         float4* o = (float4*)((float*)out + (size_t)m * ldo + n);
@@ -280,8 +280,8 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
         const int row = wm * 128 + j * 16 + fr;
         const float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
         uint2 p;
-        p.x = pack_bf16x2(v0, v1);
-        p.y = pack_bf16x2(v2, v3);
+        p.x = pack_op2(v0, v1);
+        p.y = pack_op2(v2, v3);
         *(uint2*)(smem + row * 512 + ((c ^ (row & 31)) << 4) + (fq & 1) * 8) = p;
       }
     }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_op16(wf[i], xf[j], acc[i][j]);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]));
@@ -629,14 +629,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u][t], acc[t], 0, 0, 0);
+      for (int t = 0; t < MT; ++t) acc[t] = mfma_op16(wf[u], xf[u][t], acc[t]);
   }
   for (; k < kq; k += 32) {
     if (k + 32 <= kq) {
       const bf16x8 wf = *(const bf16x8*)(wp + k);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, *(const bf16x8*)(xp + (size_t)t * 16 * ldx + k), acc[t], 0, 0, 0);
+        acc[t] = mfma_op16(wf, *(const bf16x8*)(xp + (size_t)t * 16 * ldx + k), acc[t]);
     } else {                                             // 16-wide tail of the wave's range: upper k-chunks are zero
       bf16x8 wf, xz;
 #pragma unroll
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
       for (int t = 0; t < MT; ++t) {
         bf16x8 xf = xz;
         if (fq < 2) xf = *(const bf16x8*)(xp + (size_t)t * 16 * ldx + k);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[t], 0, 0, 0);
+        acc[t] = mfma_op16(wf, xf, acc[t]);
       }
     }
   }
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_skinny_kernel(const bf16_t*
     const size_t o = (size_t)(t * 16 + fr) * ldo + n0 + fq * 4;
     if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU) {
       uint2 p;
-      p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
-      p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
+      p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_op2(v0, v1);
+      p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_op2(v2, v3);
       *(uint2*)((bf16_t*)out + o) = p;
     } else if (EPI == EPI_F32_RESID) {
       float4* dst = (float4*)((float*)out + o);
@@ -781,13 +781,13 @@ __global__ __launch_bounds__(512) void gemm_ln_skinny_kernel(const float* __rest
       const float4 a = xa[u][t][0], b = xa[u][t][1];
       const float r = rstd[t];
       uint4 pk;
-      pk.x = pack_bf16x2(a.x * r * g0.x + b0.x, a.y * r * g0.y + b0.y);
-      pk.y = pack_bf16x2(a.z * r * g0.z + b0.z, a.w * r * g0.w + b0.w);
-      pk.z = pack_bf16x2(b.x * r * g1.x + b1.x, b.y * r * g1.y + b1.y);
-      pk.w = pack_bf16x2(b.z * r * g1.z + b1.z, b.w * r * g1.w + b1.w);
+      pk.x = pack_op2(a.x * r * g0.x + b0.x, a.y * r * g0.y + b0.y);
+      pk.y = pack_op2(a.z * r * g0.z + b0.z, a.w * r * g0.w + b0.w);
+      pk.z = pack_op2(b.x * r * g1.x + b1.x, b.y * r * g1.y + b1.y);
+      pk.w = pack_op2(b.z * r * g1.z + b1.z, b.w * r * g1.w + b1.w);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        acc[t][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][nb], __builtin_bit_cast(bf16x8, pk), acc[t][nb], 0, 0, 0);
+        acc[t][nb] = mfma_op16(wf[u][nb], __builtin_bit_cast(bf16x8, pk), acc[t][nb]);
     }
   }
   if (wave > 0) {
@@ -811,8 +811,8 @@ __global__ __launch_bounds__(512) void gemm_ln_skinny_kernel(const float* __rest
       }
       const float v0 = v[0] + b4.x, v1 = v[1] + b4.y, v2 = v[2] + b4.z, v3 = v[3] + b4.w;
       uint2 p;
-      p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
-      p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
+      p.x = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v0, v1) : pack_op2(v0, v1);
+      p.y = EPI == EPI_BF16_GELU ? gelu_bf16out_pack2(v2, v3) : pack_op2(v2, v3);
       *(uint2*)((bf16_t*)out + (size_t)(t * 16 + fr) * ldo + n0 + nb * 16 + fq * 4) = p;
     }
   }
@@ -932,6 +932,7 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   return launch_gemm_bf16_variant(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant, ws, ws_bytes);
 }
 
+#ifndef PG_F16
 // Strict-mode projection on split operands (X3 [M][3K], W3 [N][3K]; K = logical depth): the fused three-product kernel when its
 // 256 x 256 tiles fill the chip, else the plain GEMM over K' = 3K -- same summation order, bit-identical results
 // (PGIBBS_SPLIT3_FUSED=0 forces the plain form; tests compare the two).
@@ -944,6 +945,7 @@ int launch_gemm_split3(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const 
   if (epi == EPI_SPLIT3_GELU) return fail(1, "gemm: split-operand epilogue needs M, N multiples of 256");
   return launch_gemm_bf16(s, X3, W3, bias, out, M, N, 3 * K, 3 * K, 3 * K, ldo, epi);
 }
+#endif  // !PG_F16
 
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
                              int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws, size_t ws_bytes) {
@@ -1012,4 +1014,4 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
   return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }
 
-}  // namespace pg
+PG_OPS_END

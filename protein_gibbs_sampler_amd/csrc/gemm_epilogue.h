@@ -3,7 +3,7 @@
 #pragma once
 #include "kernels.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -53,7 +53,7 @@ __device__ __forceinline__ pg_f32x2 gelu_poly2(float x0, float x1) {
 }
 __device__ __forceinline__ uint32_t gelu_bf16out_pack2(float x0, float x1) {
   const pg_f32x2 g = gelu_poly2(x0, x1);
-  return pack_bf16x2(g[0], g[1]);
+  return pack_op2(g[0], g[1]);
 }
 
 
@@ -128,9 +128,9 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const bf16x8 xl = *(const bf16x8*)(sb + (mi0 + j) * 2048 + fo0), xh = *(const bf16x8*)(sb + (mi0 + j) * 2048 + fo1);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[j], 0, 0, 0);
+        acc[j] = mfma_op16(wh, xl, acc[j]);
+        acc[j] = mfma_op16(wl, xh, acc[j]);
+        acc[j] = mfma_op16(wh, xh, acc[j]);
       }
       continue;
     }
@@ -141,7 +141,7 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const bf16x8 xf = *(const bf16x8*)(sb + (mi0 + j) * 2048 + fo);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[j], 0, 0, 0);
+        acc[j] = mfma_op16(wf, xf, acc[j]);
       }
     }
   }
@@ -164,10 +164,10 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
       const float g0 = gelu_erf(v0), g1 = gelu_erf(v1), g2 = gelu_erf(v2), g3 = gelu_erf(v3);
 #endif
       uint2 hi, lo;
-      hi.x = pack_bf16x2(g0, g1);
-      hi.y = pack_bf16x2(g2, g3);
-      lo.x = pack_bf16x2(g0 - __uint_as_float(hi.x << 16), g1 - __uint_as_float(hi.x & 0xffff0000u));
-      lo.y = pack_bf16x2(g2 - __uint_as_float(hi.y << 16), g3 - __uint_as_float(hi.y & 0xffff0000u));
+      hi.x = pack_op2(g0, g1);
+      hi.y = pack_op2(g2, g3);
+      lo.x = pack_op2(g0 - __uint_as_float(hi.x << 16), g1 - __uint_as_float(hi.x & 0xffff0000u));
+      lo.y = pack_op2(g2 - __uint_as_float(hi.y << 16), g3 - __uint_as_float(hi.y & 0xffff0000u));
       const int n = n0 + n_loc;
       bf16_t* o3 = (bf16_t*)out + (size_t)(m0 + m_loc) * ldo + (n >> 5) * 96 + (n & 31);
       *(uint2*)o3 = lo;
@@ -178,8 +178,8 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
     const size_t o = (size_t)(m0 + m_loc) * ldo + n0 + n_loc;
     if (T::bf16out) {
       uint2 p;
-      p.x = T::gelu_bf16 ? gelu_bf16out_pack2(v0, v1) : pack_bf16x2(v0, v1);
-      p.y = T::gelu_bf16 ? gelu_bf16out_pack2(v2, v3) : pack_bf16x2(v2, v3);
+      p.x = T::gelu_bf16 ? gelu_bf16out_pack2(v0, v1) : pack_op2(v0, v1);
+      p.y = T::gelu_bf16 ? gelu_bf16out_pack2(v2, v3) : pack_op2(v2, v3);
       *(uint2*)((bf16_t*)out + o) = p;
     } else if (T::resid) {
       // x_old + (acc + bias), as the big tile's row-shaped epilogue adds them (fp32 addition commutes: same bits)
@@ -222,8 +222,8 @@ __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int w
         p.x = gelu_bf16out_pack2(v0, v1);
         p.y = gelu_bf16out_pack2(v2, v3);
       } else {
-        p.x = pack_bf16x2(v0, v1);
-        p.y = pack_bf16x2(v2, v3);
+        p.x = pack_op2(v0, v1);
+        p.y = pack_op2(v2, v3);
       }
       *(uint2*)(smem + row * 512 + (((n >> 3) ^ (row & 31)) << 4) + (n & 4) * 2) = p;
     }
@@ -260,10 +260,10 @@ __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int w
         const float g0 = gelu_erf(a[0] + b4.x), g1 = gelu_erf(a[1] + b4.y), g2 = gelu_erf(a[2] + b4.z), g3 = gelu_erf(a[3] + b4.w);
 #endif
         uint2 hi, lo;
-        hi.x = pack_bf16x2(g0, g1);
-        hi.y = pack_bf16x2(g2, g3);
-        lo.x = pack_bf16x2(g0 - __uint_as_float(hi.x << 16), g1 - __uint_as_float(hi.x & 0xffff0000u));
-        lo.y = pack_bf16x2(g2 - __uint_as_float(hi.y << 16), g3 - __uint_as_float(hi.y & 0xffff0000u));
+        hi.x = pack_op2(g0, g1);
+        hi.y = pack_op2(g2, g3);
+        lo.x = pack_op2(g0 - __uint_as_float(hi.x << 16), g1 - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack_op2(g2 - __uint_as_float(hi.y << 16), g3 - __uint_as_float(hi.y & 0xffff0000u));
         const int hr = (row >> 6) * 32 + (row & 31);
         const int off = hr * 512 + (((n >> 3) ^ (hr & 31)) << 4) + (n & 4) * 2;
         *(uint2*)(smem + off) = hi;
@@ -360,4 +360,4 @@ __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int w
   }
 }
 
-}  // namespace pg
+PG_OPS_END

@@ -25,7 +25,7 @@
 
 #include "gemm_epilogue.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 constexpr int W16_KSLOT = 64 * 1024;
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma_op16(wf[i], xf[j], acc[i][j]);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]), "v"(xf[i]));
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_bf16_w16_kernel(const bf16_t* __
   tile256_epilogue<EPI, 16>(elem, smem, wave, lane, m0, n0, bias, out, ldo);
 }
 
+#ifndef PG_F16      /* the strict mode's split operands are bf16 pairs in either build */
 // ---------------------------------------------------------------------------------------------------------------------
 // Strict precision mode: the three split-bf16 products of a projection from ONE pass over the operands.
 //   X3 [M][3K], W3 [N][3K]: per group of 32 columns X3 = [xl | xh | xh], W3 = [wh | wl | wh] (elementwise.hip store_row_bf16).
@@ -257,15 +258,15 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[u], xl[j], acc[ip * 2 + u][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = mfma_op16(wh[u], xl[j], acc[ip * 2 + u][j]);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[u], xh[j], acc[ip * 2 + u][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = mfma_op16(wl[u], xh[j], acc[ip * 2 + u][j]);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[u], xh[j], acc[ip * 2 + u][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[ip * 2 + u][j] = mfma_op16(wh[u], xh[j], acc[ip * 2 + u][j]);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -306,6 +307,8 @@ int launch_gemm_split3_w16(hipStream_t s, const bf16_t* X3, const bf16_t* W3, co
   PG_HIP(hipGetLastError());
   return 0;
 }
+
+#endif  // !PG_F16
 
 template <int ABL>
 static int launch_w16_abl(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int K, int ldx, int ldw,
@@ -355,4 +358,4 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
   return 0;
 }
 
-}  // namespace pg
+PG_OPS_END

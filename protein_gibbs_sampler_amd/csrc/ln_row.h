@@ -5,7 +5,7 @@
 #pragma once
 #include "pg_common.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 constexpr int kMaxCh = 8;  // d <= 8 * 256 = 2048
 
@@ -54,14 +54,14 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kM
     if (lane + 64 * i < nch4) {
       const int ci = lane + 64 * i;              // float4 index = columns 4 ci .. 4 ci + 3
       uint2 p;
-      p.x = pack_bf16x2(v[i].x, v[i].y);
-      p.y = pack_bf16x2(v[i].z, v[i].w);
+      p.x = pack_op2(v[i].x, v[i].y);
+      p.y = pack_op2(v[i].z, v[i].w);
       if (!split3) {
         ((uint2*)dst)[ci] = p;
       } else {
         uint2 q;
-        q.x = pack_bf16x2(__fsub_rn(v[i].x, bf16_to_f32((bf16_t)(p.x & 0xffff))), __fsub_rn(v[i].y, bf16_to_f32((bf16_t)(p.x >> 16))));
-        q.y = pack_bf16x2(__fsub_rn(v[i].z, bf16_to_f32((bf16_t)(p.y & 0xffff))), __fsub_rn(v[i].w, bf16_to_f32((bf16_t)(p.y >> 16))));
+        q.x = pack_op2(__fsub_rn(v[i].x, op16_to_f32((bf16_t)(p.x & 0xffff))), __fsub_rn(v[i].y, op16_to_f32((bf16_t)(p.x >> 16))));
+        q.y = pack_op2(__fsub_rn(v[i].z, op16_to_f32((bf16_t)(p.y & 0xffff))), __fsub_rn(v[i].w, op16_to_f32((bf16_t)(p.y >> 16))));
         uint2* o = (uint2*)dst + (ci >> 3) * 24 + (ci & 7);      // group of 32 columns = 96 values = 24 uint2
         o[0] = q;
         o[8] = p;
@@ -70,4 +70,4 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kM
     }
 }
 
-}  // namespace pg
+PG_OPS_END

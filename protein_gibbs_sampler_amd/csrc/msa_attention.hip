@@ -17,7 +17,7 @@
 // the query chunks of one (msa, head) are placed on one XCD so the re-streamed tiles hit its L2.
 #include "kernels.h"
 
-namespace pg {
+PG_OPS_BEGIN
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
         for (int kb = 0; kb < MAXKB; ++kb) {
           const int krow = kb * 16 + fr;
           const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((kk * 4 + fq) ^ (krow & 7)) << 4));
-          st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, kk ? qf1 : qf0, st[kb], 0, 0, 0);
+          st[kb] = mfma_op16(kf, kk ? qf1 : qf0, st[kb]);
         }
       }
     }
@@ -182,10 +182,10 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
   #pragma unroll
     for (int c = 0; c < MAXKB / 2; ++c) {
       const f32x4 lo = st[2 * c], hi = st[2 * c + 1];
-      pf[c].u[0] = pack_bf16x2(lo[0] * inv, lo[1] * inv);
-      pf[c].u[1] = pack_bf16x2(lo[2] * inv, lo[3] * inv);
-      pf[c].u[2] = pack_bf16x2(hi[0] * inv, hi[1] * inv);
-      pf[c].u[3] = pack_bf16x2(hi[2] * inv, hi[3] * inv);
+      pf[c].u[0] = pack_op2(lo[0] * inv, lo[1] * inv);
+      pf[c].u[1] = pack_op2(lo[2] * inv, lo[3] * inv);
+      pf[c].u[2] = pack_op2(hi[0] * inv, hi[1] * inv);
+      pf[c].u[3] = pack_op2(hi[2] * inv, hi[3] * inv);
     }
     if (mode == 3) {
 #pragma unroll
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
             vf.h2[hh] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(
                                                       (__attribute__((address_space(3))) char*)a)));
           }
-          o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[c].v, o[db], 0, 0, 0);
+          o[db] = mfma_op16(vf.v, pf[c].v, o[db]);
         }
       }
       const int q = q0 + fr;
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(NW * 64) void msa_row_attention_kernel(
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           uint2 p;
-          p.x = pack_bf16x2(o[db][0], o[db][1]);
-          p.y = pack_bf16x2(o[db][2], o[db][3]);
+          p.x = pack_op2(o[db][0], o[db][1]);
+          p.y = pack_op2(o[db][2], o[db][3]);
           *(uint2*)(dst + db * 16) = p;
         }
       }
@@ -318,4 +318,4 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
   return 0;
 }
 
-}  // namespace pg
+PG_OPS_END

@@ -34,14 +34,55 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   uint32_t r = 0x7fffu + ((x.u >> 16) & 1u);
   return (bf16_t)((x.u + r) >> 16);
 }
+// ---- operand flavour ------------------------------------------------------------------------------
+// Every kernel family that stores or multiplies 16-bit operands (GEMMs, attention, LayerNorm / embedding outputs) is compiled
+// TWICE from the same source: with bf16 operands (namespace pg::opbf16, inline: the default every unqualified call resolves to)
+// and, with -DPG_F16, with IEEE fp16 operands (namespace pg::opf16; precision mode PG_PREC_F16).  v_mfma_f32_16x16x32_f16 runs
+// at the bf16 rate and fp16 carries 3 more mantissa bits: the 16-bit roundings of weights, LayerNorm outputs, q/k/v, softmax
+// numerators, context and FFN rows shrink 8x (profiles/r04_rounding_ablation.txt).  The flavour-dependent primitives are the
+// four below; everything else moves 16-bit words without looking at them.  (The strict mode's split operands stay bf16 pairs.)
+#ifdef PG_F16
+#define PG_OPS_NS_OPEN namespace opf16 {
+#else
+#define PG_OPS_NS_OPEN inline namespace opbf16 {
+#endif
+#define PG_OPS_BEGIN namespace pg { inline namespace opbf16 {} namespace opf16 {} PG_OPS_NS_OPEN
+#define PG_OPS_END } }
 #if defined(__HIPCC__)
+inline namespace opbf16 {}
+namespace opf16 {}
+PG_OPS_NS_OPEN
+typedef __attribute__((ext_vector_type(8))) __bf16 pg_op16x8_t;      // 8 operand values = one 16-byte fragment (raw 16-bit lanes)
+#ifdef PG_F16
+// device: v_cvt_pk_f16_f32 (round-to-nearest-even).  No saturation: |x| > 65504 becomes inf -- the 16-bit tensors of this forward
+// (LayerNorm outputs, q/k/v, softmax numerators in [0, 1], context, GELU(fc1)) stay orders of magnitude below that.
+typedef _Float16 pg_f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 pg_f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
+  pg_f16x2_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ bf16_t f32_to_op16_dev(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float op16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) float mfma_op16(pg_op16x8_t a, pg_op16x8_t b,
+                                                                               __attribute__((ext_vector_type(4))) float c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pg_f16x8_t, a), __builtin_bit_cast(pg_f16x8_t, b), c, 0, 0, 0);
+}
+#else
 // device: the cast lowers to gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even)
 typedef __bf16 pg_bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+__device__ __forceinline__ uint32_t pack_op2(float lo, float hi) {
   pg_bf16x2_t v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ bf16_t f32_to_bf16_dev(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ bf16_t f32_to_op16_dev(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ float op16_to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) float mfma_op16(pg_op16x8_t a, pg_op16x8_t b,
+                                                                               __attribute__((ext_vector_type(4))) float c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#endif
+}  // the flavour namespace
 
 // Reductions over the four lanes {l, l^16, l^32, l^48} (the four 16-lane rows of a wave = the fq groups of an MFMA
 // fragment) with gfx950's row-swap VALU instructions instead of two ds_bpermute round trips through the LDS pipe:

@@ -18,7 +18,7 @@ class NativeMaskedLM:
     def __init__(self, cfg, state_dict, precision="bf16"):
         self.cfg = dict(cfg)
         self.state_dict = state_dict       # name -> float32 ndarray (host master copy)
-        self.precision = {"bf16": _lib.PG_PREC_BF16, "fp32": _lib.PG_PREC_FP32}[precision]
+        self.precision = {"bf16": _lib.PG_PREC_BF16, "fp32": _lib.PG_PREC_FP32, "fp16": _lib.PG_PREC_F16}[precision]
         self._h = None
         self.device = "cpu"
 

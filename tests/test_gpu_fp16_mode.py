@@ -1,0 +1,158 @@
+"""PG_PREC_F16: the throughput mode's kernels compiled a second time with IEEE fp16 operands (csrc/pg_common.h, namespace
+pg::opf16).  Kernel level: every GEMM dispatch branch, the fused attention and the two MSA attention blocks
+through their C-ABI debug entries against float64 numpy on fp16-rounded inputs -- the tolerances are the bf16 tests' divided by
+the 8x finer mantissa.  Engine level: a small ESM-1b and a small ESM-MSA-1b against the fp32 oracle (the fp16 engine must be
+several times closer than the bf16 engine on the same input), and a Gibbs run whose every draw replays bit-exactly through
+oracle.draw from the logits the fp16 engine emitted (positions, scatter, draw and write-back do not depend on the mode)."""
+import random
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import draw as odraw
+from oracle.esm_forward import EsmConfig, esm1b_forward
+from protein_gibbs_sampler_amd import _lib, esm_sampler, models, weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _f16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x * 0.7071067811865476))
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 256, 128, 0), (513, 1280, 1280, 0), (1000, 512, 5120, 1), (27, 1280, 1280, 0), (16, 3840, 1280, 1),
+                                       (513, 1280, 1280, 2), (40, 1280, 5120, 2), (2048, 1280, 5120, 2), (2048, 2304, 192, 4),
+                                       (513, 1280, 1280, 3), (700, 1280, 320, 4), (8192 + 256, 4096 + 256, 320, 4), (16384, 2304, 128, 3),
+                                       (66048, 1280, 128, 2), (34048, 1280, 320, 3)])
+def test_gemm_f16_operands(M, N, K, epi):
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
+    x[:, 0] += np.arange(M, dtype=np.float32) * (0.01 if M < 4096 else 1e-4)
+    b = rng.standard_normal(N, dtype=np.float32)
+    out = rng.standard_normal((M, N), dtype=np.float32) * 3
+    res0 = out.astype(np.float64)
+    _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_F16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
+    rows = np.arange(M) if M <= 8448 else np.r_[0:300, M // 2:M // 2 + 300, M - 700:M]
+    ref = _f16(x[rows]).astype(np.float64) @ _f16(w).astype(np.float64).T + b
+    if epi in (1, 4):
+        ref = _gelu(ref)
+    if epi == 2:
+        ref = ref + res0[rows]
+    got = out[rows]
+    if epi >= 3:                                               # fp16 result: half an ulp (2^-12 relative) on top
+        assert (np.abs(got - ref) <= 2e-3 * max(1.0, np.abs(ref).max()) + np.abs(ref) * 2.0 ** -11).all()
+        assert (got == _f16(got)).all()
+        return
+    assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_f16_is_closer_to_fp32_than_bf16():
+    """The point of the mode: on the same fp32 operands the fp16-operand product is ~8x closer to the exact one."""
+    rng = np.random.default_rng(5)
+    M, N, K = 1024, 1280, 1280
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(0.025)
+    b = np.zeros(N, dtype=np.float32)
+    exact = x.astype(np.float64) @ w.astype(np.float64).T
+    errs = {}
+    for name, prec in (("bf16", _lib.PG_PREC_BF16), ("fp16", _lib.PG_PREC_F16)):
+        out = np.zeros((M, N), dtype=np.float32)
+        _lib.check(_lib.lib().pg_dbg_gemm(0, prec, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, 0))
+        errs[name] = np.abs(out - exact).mean()
+    print("\nmean |GEMM error| vs float64: bf16 operands %.3e, fp16 operands %.3e" % (errs["bf16"], errs["fp16"]))
+    assert errs["fp16"] * 5 < errs["bf16"]
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 27, 2), (3, 258, 2), (1, 16, 1), (1, 300, 2), (1, 577, 1), (2, 700, 2)])
+def test_attention_f16_operands(B, T, H):
+    rng = np.random.default_rng(T)
+    d = H * 64
+    qkv = rng.standard_normal((B, T, 3 * d), dtype=np.float32)
+    qkv[..., :d] *= 0.35
+    ctx = np.empty((B, T, d), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_attention(0, _lib.PG_PREC_F16, _lib.ptr(qkv), _lib.ptr(ctx), B, T, H))
+    r = _f16(qkv).astype(np.float64)
+    q, k, v = (r[..., i * d:(i + 1) * d].reshape(B, T, H, 64).transpose(0, 2, 1, 3) for i in range(3))
+    a = q @ k.transpose(0, 1, 3, 2)
+    p = np.exp(a - a.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, T, d)
+    assert np.abs(ctx - ref).max() < 4e-3, np.abs(ctx - ref).max()      # bf16 kernel: 2.5e-2
+    assert np.abs(ctx - ref).mean() < 4e-4                               # bf16 kernel: 3e-3
+    assert (ctx == _f16(ctx)).all()
+
+
+@pytest.mark.parametrize("which,B,R,C,H", [(4, 1, 8, 40, 2), (4, 2, 32, 257, 2), (4, 1, 128, 513, 1), (5, 1, 8, 40, 2), (5, 2, 32, 257, 2)])
+def test_msa_attention_f16_operands(which, B, R, C, H):
+    rng = np.random.default_rng(R * C + which)
+    d = H * 64
+    qkv = rng.standard_normal((B, R, C, 3 * d), dtype=np.float32)
+    scale = 0.125 / np.sqrt(R)
+    if which == 5:
+        qkv[..., :d] *= 0.125
+    ctx = np.empty((B, R, C, d), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_msa_attention(0, which, _lib.ptr(qkv), _lib.ptr(ctx), B, R, C, H, float(scale)))
+    r = _f16(qkv).astype(np.float64)
+    q, k, v = (r[..., i * d:(i + 1) * d].reshape(B, R, C, H, 64) for i in range(3))
+    if which == 4:      # tied row attention: one C x C map per (b, h) from the scores summed over the rows
+        a = np.einsum("brihd,brjhd->bhij", q, k) * scale
+        p = np.exp(a - a.max(-1, keepdims=True))
+        p /= p.sum(-1, keepdims=True)
+        ref = np.einsum("bhij,brjhd->brihd", p, v).reshape(B, R, C, d)
+    else:               # column attention: over the R rows of every column
+        a = np.einsum("bichd,bjchd->bchij", q, k)
+        p = np.exp(a - a.max(-1, keepdims=True))
+        p /= p.sum(-1, keepdims=True)
+        ref = np.einsum("bchij,bjchd->bichd", p, v).reshape(B, R, C, d)
+    err = np.abs(ctx - ref)
+    assert err.max() < 6e-3 and err.mean() < 5e-4, (err.max(), err.mean())
+
+
+def test_small_esm1b_fp16_engine_against_the_oracle_and_the_bf16_engine():
+    cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=256, n_layers=6, d_ffn=1024, max_positions=300)
+    sd = weights.synthetic_state_dict(cfg, seed=5, std=0.05, embed_std=0.3, ln_jitter=0.1)
+    ocfg = EsmConfig(d_model=256, n_layers=6, n_heads=4, d_ffn=1024, max_pos=300)
+    rng = np.random.default_rng(3)
+    tok = np.concatenate([np.zeros((5, 1), np.int64), rng.integers(4, 24, (5, 256)), np.full((5, 1), 2)], axis=1)
+    tok[:, 4:200:9] = 32
+    want = esm1b_forward(sd, ocfg, tok)
+    errs = {}
+    for prec in ("bf16", "fp16"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = models.ESM1b(state_dict=sd, config=cfg, precision=prec).model.to("cuda:0")
+        got = m.forward_logits(tok)
+        assert np.isfinite(got).all()
+        errs[prec] = (np.abs(got - want).max(), np.abs(got - want).mean())
+    print("\nsmall ESM-1b (logit std %.2f): max / mean |logit err|  bf16 %.3e / %.3e   fp16 %.3e / %.3e"
+          % (want.std(), errs["bf16"][0], errs["bf16"][1], errs["fp16"][0], errs["fp16"][1]))
+    assert errs["fp16"][1] * 4 < errs["bf16"][1] and errs["fp16"][0] * 3 < errs["bf16"][0]
+
+
+def test_fp16_gibbs_run_draws_replay_through_the_oracle():
+    cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=256, n_layers=4, d_ffn=512, max_positions=128)
+    sd = weights.synthetic_state_dict(cfg, seed=5, std=0.05, embed_std=0.3, ln_jitter=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = models.ESM1b(state_dict=sd, config=cfg, precision="fp16")
+    sampler = esm_sampler.ESM_sampler(model, device="cuda:0")
+    sampler.draw_seed, sampler.record = 99, True
+    random.seed(1)
+    seed = "MEPAATGQEAEECAHSGRGEAWEEV"
+    out = sampler.generate(6, seed, batch_size=6, num_iters=4, num_positions=5, top_k=3, burnin=2, temperature=0.9, show_progress_bar=False)
+    assert len(out) == 6 and all(len(s) == 25 for s in out)
+    run = sampler.last_run[0]
+    random.seed(1)
+    ref_table = np.asarray([[random.sample(range(1, 26), 5) for _ in range(6)] for _ in range(4)])
+    assert (run["table"] == ref_table).all()
+    for it in range(4):
+        rows = run["sampled_logits"][it].reshape(-1, 33)
+        toks = odraw.draw_rows(rows, sampler.valid_aa_idx, 3, it < 2, 0.9, np.repeat(np.arange(6), 5), it, np.tile(np.arange(5), 6), 0, 99)
+        assert (toks == run["sampled_tokens"][it].reshape(-1)).all()

@@ -26,6 +26,12 @@ STRICT_TOL = 1e-3      # north_star
 BF16_MAX_ESM, BF16_AGREE_ESM, BF16_MEAN_ESM = 0.45, 0.990, 0.074
 BF16_MAX_MSA, BF16_AGREE_MSA, BF16_MEAN_MSA = 0.32, 0.985, 0.045
 BF16_MAX_CFG1 = 0.43
+# fp16-operand mode (PG_PREC_F16, round 4): the same kernels, 3 more mantissa bits.  The CPU emulation of the engine's rounding points
+# (tests/rounding_ablation.py, profiles/r04_rounding_ablation.txt) predicts max 0.041 / mean 0.0075 for ESM-1b where it predicts
+# 0.326 / 0.062 for bf16 (measured 0.30-0.35 / 0.059); bounds = that prediction with the bf16 bounds' headroom.
+F16_MAX_ESM, F16_AGREE_ESM, F16_MEAN_ESM = 0.07, 0.997, 0.0095
+F16_MAX_MSA, F16_AGREE_MSA, F16_MEAN_MSA = 0.05, 0.996, 0.006
+F16_MAX_CFG1 = 0.07
 
 
 def _kl_valid(got, want, valid):
@@ -53,7 +59,7 @@ def esm_case():
     return cfg, sd, tok, want
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_esm1b_full_size_all_logits(esm_case, precision):
     cfg, sd, tok, want = esm_case
     with warnings.catch_warnings():
@@ -74,12 +80,15 @@ def test_esm1b_full_size_all_logits(esm_case, precision):
         assert err.max() < STRICT_TOL
         assert agree > 0.999            # flips only between near-tied logits (gap < 2e-3)
         assert kl.max() < 1e-6
+    elif precision == "fp16":
+        assert err.max() < F16_MAX_ESM and agree >= F16_AGREE_ESM and err.mean() < F16_MEAN_ESM
+        assert kl.mean() < 1.5e-5 and kl.max() < 4e-4          # the KL scales with the squared logit error: 64x below bf16's
     else:
         assert err.max() < BF16_MAX_ESM and agree >= BF16_AGREE_ESM and err.mean() < BF16_MEAN_ESM
         assert kl.mean() < 6e-4 and kl.max() < 1.5e-2          # measured 2.9e-4 / 4.7e-3 (ESM-1b), 2.4e-4 / 3.6e-3 (MSA-1b)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_esm1b_full_size_against_huggingface(precision):
     """The engine at the REAL ESM-1b sizes against logits recorded from HuggingFace's EsmForMaskedLM (tests/golden/esm_hf_full.npz,
     generator tests/golden/make_golden.py hf_full: an implementation of the architecture that shares no code and no author with
@@ -102,6 +111,8 @@ def test_esm1b_full_size_against_huggingface(precision):
           % (precision, err.max(), err.mean(), z["logits"].std(), agree))
     if precision == "fp32":
         assert err.max() < STRICT_TOL and agree > 0.999
+    elif precision == "fp16":
+        assert err.max() < F16_MAX_ESM and agree >= 0.994 and err.mean() < F16_MEAN_ESM
     else:
         # measured 0.310 / mean 0.0604 / agreement 0.9845 (8 of 516 rows: these chains carry 10 % and 20 % masks -- more near-ties)
         assert err.max() < BF16_MAX_ESM and agree >= 0.975 and err.mean() < BF16_MEAN_ESM
@@ -122,7 +133,7 @@ def msa_case():
     return cfg, sd, tok, want
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_msa1b_full_size_all_logits(msa_case, precision):
     cfg, sd, tok, want = msa_case
     with warnings.catch_warnings():
@@ -142,12 +153,15 @@ def test_msa1b_full_size_all_logits(msa_case, precision):
         assert err.max() < STRICT_TOL
         assert agree > 0.999            # flips only between near-tied logits (gap < 2e-3)
         assert kl.max() < 1e-6
+    elif precision == "fp16":
+        assert err.max() < F16_MAX_MSA and agree >= F16_AGREE_MSA and err.mean() < F16_MEAN_MSA
+        assert kl.mean() < 1.5e-5 and kl.max() < 4e-4
     else:
         assert err.max() < BF16_MAX_MSA and agree >= BF16_AGREE_MSA and err.mean() < BF16_MEAN_MSA
         assert kl.mean() < 6e-4 and kl.max() < 1.5e-2          # measured 2.9e-4 / 4.7e-3 (ESM-1b), 2.4e-4 / 3.6e-3 (MSA-1b)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_config1_full_size_single_chain(esm_case, precision):
     """BASELINE configuration 1 on the REAL ESM-1b shape: one chain of L = 25 (T = 27 tokens), 20 iterations, 10 % of the positions
     (P = 2) per iteration, top_k = 1, burnin = 10 -- the weight-streaming (skinny GEMM) + hipGraph regime of the engine.  Every
@@ -184,7 +198,7 @@ def test_config1_full_size_single_chain(esm_case, precision):
         assert (want == run["sampled_tokens"][it].reshape(-1)).all()
         tok[0, table[it, 0]] = want
     print("\n[config 1, ESM-1b 33 x 1280, %s] max|engine - oracle| over 20 iterations = %.3e" % (precision, worst))
-    assert worst < (STRICT_TOL if precision == "fp32" else BF16_MAX_CFG1)
+    assert worst < {"fp32": STRICT_TOL, "bf16": BF16_MAX_CFG1, "fp16": F16_MAX_CFG1}[precision]
     assert (tok == run["tokens"]).all() and out == s.untokenize_batch(torch_from(tok), True, True)
     # the unrecorded run replays the loop from one captured hipGraph: same strings
     s.record = False
