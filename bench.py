@@ -372,42 +372,76 @@ def main():
             assert same, "sharded result differs from the single-GPU result"
         dist.barrier()
 
+    def executed_flops_per_iter():
+        """What one iteration launches: every layer's four GEMMs on all B*T rows except the LAST layer's out-proj / fc1 / fc2, which
+        run on the B*P sampled rows only (exact pruning); attention on all rows; the LM head at the sampled rows."""
+        d_, f_, nl_, V_ = cfg["d_model"], cfg["d_ffn"], cfg["n_layers"], cfg["vocab"]
+        full = 2.0 * (4 * d_ * d_ + 2 * d_ * f_) * (B * T)
+        last = 2.0 * (3 * d_ * d_) * (B * T) + 2.0 * (d_ * d_ + 2 * d_ * f_) * (B * P)
+        gemm = (nl_ - 1) * full + last
+        return gemm, gemm + nl_ * 4.0 * T * d_ * (B * T) + (2.0 * d_ * d_ + 2.0 * V_ * d_) * (B * P)
+
     if rank == 0 and not dry:
         n_tok, n_samp = B * T, B * P
-        flops_iter = total_flops_per_iter(cfg, n_tok, T, n_samp) * (3 if args.precision == "fp32" else 1)
+        mult = 3 if args.precision == "fp32" else 1          # strict mode: three bf16 MFMA products per product
         out["model_tflops_per_gpu"] = total_flops_per_iter(cfg, n_tok, T, n_samp) * K / elapsed / 1e12
-        out["executed_tflops_per_gpu"] = flops_iter * K / elapsed / 1e12
+        out["executed_tflops_per_gpu"] = executed_flops_per_iter()[1] * mult * K / elapsed / 1e12     # last layer pruned: ~2 % below the model's
         out["frac_of_bf16_mfma_peak"] = out["executed_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS
     if not dry and not args.no_roofline:
-        # dominant kernel family = the bf16 MFMA GEMM; HIP events on the engine's stream around every launch
+        # HIP events on the engine's stream around every launch, per kernel class (pg_prof_*)
         lm.prof_enable(True)
         lm.prof_reset()
         n_prof = min(K, 3)
         keep = job.run(n_prof)
         torch.cuda.synchronize(dev)
-        ms, launches = lm.prof_get("gemm")
-        parts = {c: lm.prof_get(c) for c in ("gemm", "attention", "layernorm", "embed", "head", "sample")}
+        classes = ("gemm", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_other", "attention", "layernorm", "embed", "head", "sample")
+        parts = {c: lm.prof_get(c) for c in classes}
+        ms, launches = parts["gemm"]
         lm.prof_enable(False)
-        if rank == 0 and launches and args.precision == "bf16":
-            # FLOPs the GEMM launches actually executed: every layer on all B*T rows, except that the last layer's
-            # out-proj / fc1 / fc2 run on the B*P sampled rows only (exact pruning); head GEMM timed under "head"
-            d_, f_, nl_ = cfg["d_model"], cfg["d_ffn"], cfg["n_layers"]
-            full = 2.0 * (4 * d_ * d_ + 2 * d_ * f_) * (B * T)
-            last = 2.0 * (3 * d_ * d_) * (B * T) + 2.0 * (d_ * d_ + 2 * d_ * f_) * (B * P)
-            gf = ((nl_ - 1) * full + last) * n_prof
-            achieved = gf / (ms * 1e-3) / 1e12
+        if rank == 0 and launches and args.precision in ("bf16", "fp16"):
+            d_, f_, Mr = cfg["d_model"], cfg["d_ffn"], B * T
+            el = 2                                                     # bytes per 16-bit operand
+            # per launch: FLOPs and ALGORITHMIC bytes (operands read once + outputs written once; the residual GEMMs read and
+            # write the fp32 stream) -- derived from the shapes, DESIGN.md section 4's table
+            shapes = {"gemm_qkv": (Mr, 3 * d_, d_, Mr * d_ * el + 3 * d_ * d_ * el + Mr * 3 * d_ * el),
+                      "gemm_out": (Mr, d_, d_, Mr * d_ * el + d_ * d_ * el + 2 * Mr * d_ * 4),
+                      "gemm_fc1": (Mr, f_, d_, Mr * d_ * el + f_ * d_ * el + Mr * f_ * el),
+                      "gemm_fc2": (Mr, d_, f_, Mr * f_ * el + d_ * f_ * el + 2 * Mr * d_ * 4)}
+            per = {}
+            for name, (m_, n_, k_, nbytes) in shapes.items():
+                t_ms, n_l = parts[name]
+                if n_l:
+                    fl = 2.0 * m_ * n_ * k_
+                    per[name] = {"launches_per_iter": n_l // n_prof, "avg_launch_us": 1e3 * t_ms / n_l, "gflop_per_launch": fl / 1e9,
+                                 "algorithmic_MB_per_launch": nbytes / 1e6, "tflops": fl / (t_ms / n_l * 1e-3) / 1e12,
+                                 "frac_of_mfma_peak": fl / (t_ms / n_l * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                 "algorithmic_TB_per_s": nbytes / (t_ms / n_l * 1e-3) / 1e12}
+            gf = executed_flops_per_iter()[0] * n_prof
+            family = gf / (ms * 1e-3) / 1e12
+            dom = max(per, key=lambda k_: parts[k_][0]) if per else None           # the kernel the iteration spends most time in
             traffic, traffic_src = measured_gemm_traffic()
-            out["roofline"] = {"bound": "mfma", "kernel": "bf16 MFMA GEMM family (all %d launches/iteration)" % (launches // n_prof),
-                               "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated; %s), avg over the per-layer "
-                                               "GEMMs; algorithmic minimum 0.63 GB/launch" % traffic_src,
-                               "avg_launch_ms": ms / launches, "flops_per_launch": gf / launches,
+            alg_avg = (sum(per[k_]["algorithmic_MB_per_launch"] * per[k_]["launches_per_iter"] for k_ in per)
+                       / max(1, sum(per[k_]["launches_per_iter"] for k_ in per)) * 1e6) if per else None
+            kname = {"gemm_qkv": "QKV projection (gemm_bf16_w16_kernel<EPI_BF16>)", "gemm_out": "attention out-projection (gemm_bf16_pp_kernel<EPI_F32_RESID>)",
+                     "gemm_fc1": "fc1 + GELU (gemm_bf16_w16_kernel<EPI_BF16_GELU>)", "gemm_fc2": "fc2 (gemm_bf16_pp_kernel<EPI_F32_RESID>)"}
+            out["roofline"] = {"bound": "mfma", "kernel": kname.get(dom, "bf16 MFMA GEMM"),
+                               "achieved": per[dom]["tflops"] if dom else family, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": (per[dom]["tflops"] if dom else family) / MFMA_BF16_PEAK_TFLOPS,
+                               "traffic": traffic,
+                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated; %s), avg over the per-layer GEMM launches; "
+                                               "algorithmic bytes of the same launches, from the shapes: %.0f (per kernel below)"
+                                               % (traffic_src, alg_avg or 0),
+                               "avg_launch_ms": (per[dom]["avg_launch_us"] / 1e3) if dom else ms / launches,
+                               "flops_per_launch": (per[dom]["gflop_per_launch"] * 1e9) if dom else gf / launches,
+                               "gemm_family": {"achieved": family, "frac": family / MFMA_BF16_PEAK_TFLOPS, "launches_per_iter": launches // n_prof,
+                                               "avg_launch_ms": ms / launches, "executed_gemm_tflop_per_iter": gf / n_prof / 1e12},
+                               "per_kernel": per,
                                "peak_note": "peak = dense bf16 MFMA rate at 2.4 GHz; under this load the shader clock measured inside "
                                             "the GEMM main loop is ~1.72 GHz (power limit: 2.29 GHz with all-zero operands), "
                                             "profiles/r02_gemm_clock_probe.txt"}
         if rank == 0:
-            out["time_split_ms_per_iter"] = {c: v[0] / n_prof for c, v in parts.items()}
+            out["time_split_ms_per_iter"] = {c: parts[c][0] / n_prof for c in ("gemm", "attention", "layernorm", "embed", "head", "sample")}
+            out["time_split_ms_per_iter"]["gemm_by_projection"] = {c: parts[c][0] / n_prof for c in ("gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_other")}
 
     # ---- N = 1 extras: strict-mode leg, config 1 on the GPU, CPU baseline ------------------------------------------------
     lm_strict = None

@@ -417,17 +417,18 @@ int pg_prof_reset(pg_engine* h) {
 }
 int pg_prof_get(pg_engine* h, const char* kernel_class, double* total_ms, int64_t* launches) {
   if (!h || !kernel_class || !total_ms || !launches) return fail(PG_ERR_INVALID, "pg_prof_get: null argument");
-  static const char* names[PC_COUNT] = {"gemm", "attention", "layernorm", "embed", "head", "sample"};
+  static const char* names[PC_COUNT] = {"gemm_other", "attention", "layernorm", "embed", "head", "sample", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2"};
   int cls = -1;
+  const bool all_gemm = !strcmp(kernel_class, "gemm");       // the whole family: the four per-layer projections + the rest
   for (int i = 0; i < PC_COUNT; ++i)
     if (!strcmp(names[i], kernel_class)) cls = i;
-  if (cls < 0) return fail(PG_ERR_INVALID, std::string("unknown kernel class ") + kernel_class);
+  if (cls < 0 && !all_gemm) return fail(PG_ERR_INVALID, std::string("unknown kernel class ") + kernel_class);
   DeviceGuard g(h->e.device);
   PG_HIP(hipStreamSynchronize(h->e.stream));
   double ms = 0;
   int64_t n = 0;
   for (auto& r : h->e.prof.recs)
-    if (r.cls == cls) {
+    if (r.cls == cls || (all_gemm && (r.cls == PC_GEMM || r.cls >= PC_GEMM_QKV))) {
       float t = 0;
       PG_HIP(hipEventElapsedTime(&t, r.a, r.b));
       ms += t;

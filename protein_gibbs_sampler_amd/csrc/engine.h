@@ -28,7 +28,8 @@ struct Prof {
   void destroy();
 };
 
-enum ProfClass { PC_GEMM = 0, PC_ATTN, PC_LN, PC_EMBED, PC_HEAD, PC_SAMPLE, PC_COUNT };
+// PC_GEMM_*: the four per-layer projections of a full-batch forward, timed apart (bench.py's per-kernel roofline); "gemm" = all five
+enum ProfClass { PC_GEMM = 0, PC_ATTN, PC_LN, PC_EMBED, PC_HEAD, PC_SAMPLE, PC_GEMM_QKV, PC_GEMM_OUT, PC_GEMM_FC1, PC_GEMM_FC2, PC_COUNT };
 
 struct DenseW {   // y = x W^T + b ; W bf16 [N][K], b fp32 [N].  Strict precision mode: w is [N][3K], each row the
   bf16_t* w = nullptr;   // K-concatenated split-bf16 operand [hi | lo | hi] (hi = bf16(W), lo = bf16(W - hi))
@@ -66,7 +67,7 @@ struct Engine {
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
   // x (+)= a W^T + b, then h = LayerNorm(x; ln): residual GEMM + LayerNorm kernel
   int resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
-                    float* ws = nullptr, size_t ws_bytes = 0);
+                    float* ws = nullptr, size_t ws_bytes = 0, int prof_class = PC_GEMM);
   DevBuf tmp_idx, tmp_out;                 // batched generate_single on small MSAs: one template's step table / outputs
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask

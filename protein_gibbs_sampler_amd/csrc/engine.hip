@@ -337,7 +337,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     if (ln_in_gemm) {
       if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_ln_skinny, stream, X, d, L.ln1.g, L.ln1.b, eps, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, 3 * d, EPI_BF16); }))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+      if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     }
     if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_bf16, stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
@@ -369,12 +369,12 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
       continue;
     }
-    if ((rc = resid_gemm_ln(CTX, L.out, X, Mi, M, d, L.ln2, Hh))) return rc;                       // x += out_proj(ctx); h = LN2(x)
-    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = resid_gemm_ln(CTX, L.out, X, Mi, M, d, L.ln2, Hh, nullptr, 0, PC_GEMM_OUT))) return rc;   // x += out_proj(ctx); h = LN2(x)
+    if ((rc = timed(PC_GEMM_FC1, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
     if (l + 1 < cfg.n_layers) {                                                                    // x += fc2(ffn); h = LN1 of the next layer
-      if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, esm_layers[l + 1].ln1, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes))) return rc;
+      if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, esm_layers[l + 1].ln1, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes, PC_GEMM_FC2))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM_FC2, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
     }
   }
   return PG_OK;
@@ -384,9 +384,9 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
 // picks, followed by the LayerNorm kernel at its HBM roofline.  (Normalising inside the GEMM was built in round 3, bit-identical
 // and slower; it left the library in round 4: tools/probes/gemm_ln_fused.hip.)
 int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
-                          float* ws, size_t ws_bytes) {
+                          float* ws, size_t ws_bytes, int prof_class) {
   const int d = W.N, K = W.K;
-  int rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
+  int rc = timed(prof_class, [&] { return OPS(launch_gemm_bf16, stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
   if (rc) return rc;
   return timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps); });
 }
@@ -570,7 +570,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   for (int l = 0; l < cfg.n_layers; ++l) {
     const MsaLayer& L = msa_layers[l];
     // tied row attention
-    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if (C <= 576) {
       float* part = nullptr;
       // few workgroups: give the kernel scratch for its split-R mode (decided on the job's batch: the split changes the
@@ -597,9 +597,9 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       });
       if (rc) return rc;
     }
-    if ((rc = resid_gemm_ln(CTX, L.row_out, X, Mi, M, d, L.ln_col, Hh))) return rc;                 // x += row_out(ctx); h = LN_col(x)
+    if ((rc = resid_gemm_ln(CTX, L.row_out, X, Mi, M, d, L.ln_col, Hh, nullptr, 0, PC_GEMM_OUT))) return rc;                 // x += row_out(ctx); h = LN_col(x)
     // column attention (q pre-scaled by dh^-0.5 in the weights)
-    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+    if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_seq_bf16, stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: nothing but the selected rows is read again -> finish column out-projection and FFN on n_sel rows
@@ -620,13 +620,13 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, ffn_sel.as<bf16_t>(), L.fc2.w, L.fc2.b, XS, Ni, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Ni, d, batch_rows), splitk.bytes); }))) return rc;
       break;
     }
-    if ((rc = resid_gemm_ln(CTX, L.col_out, X, Mi, M, d, L.ln_ffn, Hh))) return rc;                 // x += col_out(ctx); h = LN_ffn(x)
+    if ((rc = resid_gemm_ln(CTX, L.col_out, X, Mi, M, d, L.ln_ffn, Hh, nullptr, 0, PC_GEMM_OUT))) return rc;                 // x += col_out(ctx); h = LN_ffn(x)
     // feed forward
-    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = timed(PC_GEMM_FC1, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
     if (l + 1 < cfg.n_layers) {                                                                      // x += fc2(ffn); h = LN_row of the next layer
-      if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, msa_layers[l + 1].ln_row, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes))) return rc;
+      if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, msa_layers[l + 1].ln_row, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes, PC_GEMM_FC2))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM_FC2, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
     }
   }
   return PG_OK;
