@@ -98,7 +98,12 @@ typedef struct {
   float layer_norm_eps;  /* 1e-5 */
 } pg_model_config;
 
-/* one fp32 tensor of a fair-esm state dict, by its fair-esm key */
+/* one fp32 tensor of a fair-esm state dict, by its fair-esm key.
+ * The decoder is tied: logits = LN(gelu(dense(x))) . embed_tokens^T + lm_head.bias.  fair-esm zeroes the <mask> row of
+ * embed_tokens when it loads an ESM-1b checkpoint (token dropout), and the Python loader (weights.load_fair_esm_checkpoint) does
+ * the same -- so after a real ESM-1b checkpoint load logit[<mask>] = lm_head.bias[<mask>] only.  The samplers never draw <mask>
+ * (not in valid_idx); log-likelihoods normalise over all V logits including that bias-only term, as fair-esm does.  Tensors
+ * handed to pg_engine_create directly are used as given. */
 typedef struct {
   const char* name;
   const float* data;
