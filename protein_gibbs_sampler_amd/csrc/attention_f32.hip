@@ -201,8 +201,13 @@ struct SplitAttn {
   }
 };
 
-// ---- full attention: one workgroup = (sequence, head, 64 queries), wave w owns queries q0 .. q0+15 -----------------
-template <int MAXKB>
+// ---- full attention: one workgroup = (sequence, head, 64 * NQB queries); wave w owns the 16-query blocks w, w + 4, ... of the
+// chunk.  The K / V tiles are read from HBM / L2 and split ONCE per workgroup and tile and every query block of the chunk runs
+// against them, its online-softmax state (O, m, l: 18 registers) carried across the tiles: at T = 258 one workgroup per
+// (sequence, head) instead of five that each re-staged and re-split the same 132 KB of fp32 K and V (round 3: 28 ms of the strict
+// config-2 iteration were this kernel, 4x the bf16 mode's, most of it the 5x redundant fp32 tile traffic).  The per-query
+// arithmetic (tile order, products, rounding points) is unchanged: identical bits.
+template <int MAXKB, int NQB>
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(
     const float* __restrict__ qkv, bf16_t* __restrict__ ctx, int split_d, int T, int H, int ld_qkv_, int ld_ctx_, int k_off,
     int v_off, SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok, int pad_idx) {
@@ -217,45 +222,56 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
   const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
   const float* base = qkv + row0 * ld_qkv_ + h * 64;
   const int fr = lane & 15, fq = lane >> 4;
-  const int q0 = qc * 64 + wave * 16;
-  const bool active = q0 < T;                        // wave-uniform
-  bf16x8 qh[2], ql[2];
-  A::load_q(base + (size_t)(q0 + fr < T ? q0 + fr : T - 1) * ld_qkv, fq, qh, ql);
-  f32x4 o[4];
+  const int qbase = qc * (64 * NQB) + wave * 16;     // block j of this wave: queries qbase + j*64 .. +15
+  f32x4 o[NQB][4];
+  float m[NQB], l[NQB];
 #pragma unroll
-  for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m = -3.0e38f, l = 0.f;
+  for (int j = 0; j < NQB; ++j) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[j][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m[j] = -3.0e38f;
+    l[j] = 0.f;
+  }
 
   for (int k0 = 0; k0 < T; k0 += tpad) {
     __syncthreads();
     A::stage(base + (size_t)k0 * ld_qkv + k_off, ld_qkv, T - k0, Kh, Kl, tid);
     A::stage(base + (size_t)k0 * ld_qkv + v_off, ld_qkv, T - k0, Vh, Vl, tid);
     __syncthreads();
-    if (!active) continue;
-    f32x4 st[MAXKB];
-#pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    A::qk(Kh, Kl, qh, ql, st, fr, fq);
     const int tl = T - k0 - fq * 4;              // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
 #pragma unroll
-    for (int kb = 0; kb < MAXKB; ++kb)
+    for (int j = 0; j < NQB; ++j) {
+      const int q0 = qbase + j * 64;
+      if (q0 >= T) continue;                       // wave-uniform
+      bf16x8 qh[2], ql[2];
+      A::load_q(base + (size_t)(q0 + fr < T ? q0 + fr : T - 1) * ld_qkv, fq, qh, ql);
+      f32x4 st[MAXKB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
-    if (key_tok) {                               // <pad> keys of a ragged batch (key_tok = token buffer, sequence seq at seq*T)
-      const int32_t* kt = key_tok + (size_t)seq * T + k0;
+      for (int kb = 0; kb < MAXKB; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      A::qk(Kh, Kl, qh, ql, st, fr, fq);
 #pragma unroll
       for (int kb = 0; kb < MAXKB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kb * 16 + fq * 4 + r;
-          if (k0 + key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
-        }
+        for (int r = 0; r < 4; ++r)
+          if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
+      if (key_tok) {                               // <pad> keys of a ragged batch (key_tok = token buffer, sequence seq at seq*T)
+        const int32_t* kt = key_tok + (size_t)seq * T + k0;
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kb * 16 + fq * 4 + r;
+            if (k0 + key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
+          }
+      }
+      A::softmax_pv(st, o[j], m[j], l[j], Vh, Vl, fr, fq);
     }
-    A::softmax_pv(st, o, m, l, Vh, Vl, fr, fq);
   }
-  const int q = q0 + fr;
-  if (active && q < T) A::store_ctx(o, l, ctx + row0 * ld_ctx_ + (size_t)q * ld_ctx, h, fq, split_d);
+#pragma unroll
+  for (int j = 0; j < NQB; ++j) {
+    const int q = qbase + j * 64 + fr;
+    if (qbase + j * 64 < T && q < T) A::store_ctx(o[j], l[j], ctx + row0 * ld_ctx_ + (size_t)q * ld_ctx, h, fq, split_d);
+  }
 }
 
 // ---- tied row attention (MSA), step 1: S[b,h][i][j] = scale * sum_r q_r[i] . k_r[j] ---------------------------------
@@ -556,9 +572,16 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
                          int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx) {
   if (n_seq == 0) return 0;
   if (T <= 0) return fail(1, "attention: empty sequence");
-  const int n_qchunk = (T + 63) / 64;
-  if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
   const int mode = attn_f32_mode();
+  // 16-query blocks per wave of the split kernel (its workgroup = 64 * nqb queries, all of them against each staged K / V tile):
+  // the smallest of 1, 2, 3, 5 that covers the sequence with one workgroup, else 5 (PGIBBS_ATTN_F32_NQB overrides: A/B runs)
+  static const int nqb_env = [] { const char* e = getenv("PGIBBS_ATTN_F32_NQB"); return e ? atoi(e) : 0; }();
+  const int blocks = (T + 15) / 16;
+  int nqb = blocks <= 4 ? 1 : (blocks <= 8 ? 2 : (blocks <= 12 ? 3 : 5));
+  if (nqb_env == 1 || nqb_env == 2 || nqb_env == 3 || nqb_env == 5) nqb = nqb_env;
+  if (mode < 0 || T <= 64) nqb = 1;
+  const int n_qchunk = (T + 64 * nqb - 1) / (64 * nqb);
+  if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
   const dim3 grid((unsigned)(n_seq * H * n_qchunk));
   if (mode < 0) {
     hipLaunchKernelGGL(attention_f32_kernel, grid, dim3(64), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl,
@@ -566,12 +589,14 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
   } else {
     // key tile: 64 keys for short sequences, else 160 (80 KB of LDS: two workgroups per CU; at T = 258 a single 288-key
     // tile with one workgroup per CU was 1.6x slower)
-    const int kb = T <= 64 ? 4 : 10;
-#define PG_ATT_SPLIT(KB)                                                                                                  \
-  hipLaunchKernelGGL(attention_split_kernel<KB>, grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
+#define PG_ATT_SPLIT(KB, NQ)                                                                                                  \
+  hipLaunchKernelGGL((attention_split_kernel<KB, NQ>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
                      n_qchunk, key_tok, pad_idx)
-    if (kb <= 4) PG_ATT_SPLIT(4);
-    else PG_ATT_SPLIT(10);
+    if (T <= 64) PG_ATT_SPLIT(4, 1);
+    else if (nqb == 1) PG_ATT_SPLIT(10, 1);
+    else if (nqb == 2) PG_ATT_SPLIT(10, 2);
+    else if (nqb == 3) PG_ATT_SPLIT(10, 3);
+    else PG_ATT_SPLIT(10, 5);
 #undef PG_ATT_SPLIT
   }
   PG_HIP(hipGetLastError());
