@@ -72,6 +72,12 @@ typedef struct pg_engine pg_engine;
 
 #define PG_ARCH_ESM1B 1 /* fair-esm ProteinBertModel, "ESM-1b" architecture (ESM-1b, ESM-1v) */
 #define PG_ARCH_MSA1B 2 /* fair-esm MSATransformer (esm_msa1b_t12_100M_UR50S) */
+#define PG_ARCH_ESM1 3  /* fair-esm ProteinBertModel, "ESM-1" architecture (esm1_t6_43M / t12_85M / t34_670M_UR50S: the models behind
+                           pgen.models.ESM6 / ESM12 / ESM34, /root/reference/src/pgen/models.py:69-82): embed_scale sqrt(d), sinusoidal
+                           positions (supplied as the `embed_positions.weight` table), no emb_layer_norm_before / after, one extra
+                           attention key / value per layer (`layers.i.self_attn.bias_k` / `bias_v`, d_model values each), untied output
+                           projection `embed_out.weight` [V][d] + `embed_out.bias` [V], no LM-head dense / LayerNorm, no token
+                           dropout; vocabulary of 35 (<cls> = 32, <mask> = 33).  Runs through the ESM-1b entry points. */
 
 #define PG_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream (throughput mode) */
 #define PG_PREC_F16 2  /* the throughput mode with IEEE fp16 operands instead of bf16 (same kernels, same MFMA rate; 3 more mantissa

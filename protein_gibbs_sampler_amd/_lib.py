@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpgibbs.so")
 
 PG_OK = 0
 PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_NO_DEVICE, PG_ERR_WEIGHTS, PG_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
-PG_ARCH_ESM1B, PG_ARCH_MSA1B = 1, 2
+PG_ARCH_ESM1B, PG_ARCH_MSA1B, PG_ARCH_ESM1 = 1, 2, 3
 PG_PREC_BF16, PG_PREC_FP32, PG_PREC_F16 = 0, 1, 2
 INT32_MAX = 2**31 - 1
 

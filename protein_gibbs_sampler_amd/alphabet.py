@@ -16,12 +16,19 @@ _TOKEN_RE = re.compile(r"<[a-z_0-9]+>|.")
 
 
 class Alphabet:
-    """"ESM-1b" style alphabet: <cls> <pad> <eos> <unk> + 27 residues/gap symbols + <null_1> + <mask>."""
+    """"ESM-1b" style alphabet: <cls> <pad> <eos> <unk> + 27 residues/gap symbols + <null_1> + <mask> (33 tokens), or, with
+    arch="ESM-1" (esm1_t6 / t12 / t34: pgen.models.ESM6 / ESM12 / ESM34), fair-esm's "ESM-1" table: <null_0> <pad> <eos> <unk> +
+    the same 27 symbols + <null_1> + <cls> <mask> <sep> (35 tokens: <cls> = 32, <mask> = 33; pinned by the reference's
+    test_esm_sampler.py:46,53: "AA" + 3 masks -> [32, 5, 5, 33, 33, 33])."""
 
-    def __init__(self, prepend_bos=True, append_eos=True):
+    def __init__(self, prepend_bos=True, append_eos=True, arch="ESM-1b"):
         self.standard_toks = list(PROTEINSEQ_TOKS)
-        self.prepend_toks = ["<cls>", "<pad>", "<eos>", "<unk>"]
-        self.append_toks = ["<mask>"]
+        if arch == "ESM-1":
+            self.prepend_toks = ["<null_0>", "<pad>", "<eos>", "<unk>"]
+            self.append_toks = ["<cls>", "<mask>", "<sep>"]
+        else:
+            self.prepend_toks = ["<cls>", "<pad>", "<eos>", "<unk>"]
+            self.append_toks = ["<mask>"]
         self.all_toks = list(self.prepend_toks) + list(self.standard_toks)
         while len(self.all_toks) % 8:
             self.all_toks.append("<null_%d>" % (8 - len(self.all_toks) % 8))

@@ -121,7 +121,7 @@ int pg_engine_get_stat(pg_engine* h, const char* name, int64_t* value) {
 int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, float* logits_out) {
   if (!h || !tokens || !logits_out) return fail(PG_ERR_INVALID, "pg_esm_forward_logits: null argument");
   Engine& e = h->e;
-  if (e.cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
+  if (e.cfg.arch != PG_ARCH_ESM1B && e.cfg.arch != PG_ARCH_ESM1) return fail(PG_ERR_INVALID, "engine was not built for an ESM-1b / ESM-1 architecture");
   if (B < 0 || T < 1) return fail(PG_ERR_INVALID, "bad shape");
   if (T > e.cfg.max_positions) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
   if (B == 0) return PG_OK;
@@ -362,7 +362,7 @@ static int forward_logprobs(Engine& e, bool msa, const int32_t* tokens, int B, i
 int pg_esm_forward_logprobs(pg_engine* h, const int32_t* tokens, int B, int T, const int32_t* row_of, const int32_t* idx,
                             const int32_t* targets, int n_sel, int P, float* out) {
   if (!h || !tokens || !row_of || !idx || !targets || !out) return fail(PG_ERR_INVALID, "pg_esm_forward_logprobs: null argument");
-  if (h->e.cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
+  if (h->e.cfg.arch != PG_ARCH_ESM1B && h->e.cfg.arch != PG_ARCH_ESM1) return fail(PG_ERR_INVALID, "engine was not built for an ESM-1b / ESM-1 architecture");
   if (B < 0 || T < 1 || n_sel < 0 || P < 0) return fail(PG_ERR_INVALID, "bad shape");
   if (T > h->e.cfg.max_positions) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
   return forward_logprobs(h->e, false, tokens, B, 1, T, row_of, idx, targets, n_sel, P, out);

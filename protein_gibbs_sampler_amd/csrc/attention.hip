@@ -44,7 +44,8 @@ __device__ unsigned long long* pg_att_prof;      // [workgroup][wave][8 slots][8
 template <int MAXKB, bool PADMASK>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
-                                                       SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx) {
+                                                       SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx,
+                                                       const bf16_t* __restrict__ bias_kv) {
   __shared__ __attribute__((aligned(16))) char smem[2 * MAXKB * 16 * 128];
   char* Ks = smem;
   char* Vs = smem + MAXKB * 16 * 128;          // V rows, same layout as K: row*128 + ((chunk ^ (row & 7)) << 4)
@@ -57,6 +58,8 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   const size_t row0 = (size_t)(seq / sl.inner_count) * sl.outer_rows + (size_t)(seq % sl.inner_count) * sl.inner_rows;
   const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
   const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
+  // ESM-1 (add_bias_kv): key T is the learned bias_k / bias_v of this head -- one more key, attended by every query, never masked
+  const int Tk = T + (bias_kv ? 1 : 0);
   // All MAXKB key blocks are computed unconditionally: K rows / V^T columns past T are zero-filled and
   // their scores are masked, so no wave-uniform branches (and no dynamic register indexing) are needed.
   constexpr int nkc = MAXKB / 2;
@@ -76,6 +79,9 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       if (i < tpad * 8 && row < T) {
         kreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + k_off + c * 8);
         vreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + v_off + c * 8);
+      } else if (bias_kv && row == T) {
+        kreg[it] = *(const uint4*)(bias_kv + h * 64 + c * 8);
+        vreg[it] = *(const uint4*)(bias_kv + (H + h) * 64 + c * 8);
       }
     }
 #pragma unroll
@@ -147,11 +153,11 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
     PG_T(qb >> 2, 1);
     // exact softmax over keys (lane-local + 4-lane reduction); exp(s - m) = exp2(s*log2e - m*log2e)
     float mx = -3.0e38f;
-    int tl = T - fq * 4;                      // key kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
+    int tl = Tk - fq * 4;                     // key kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
     asm volatile("" : "+v"(tl));              // keep the compares inside the loop (no hoisted lane masks)
 #pragma unroll
     for (int kb = MAXKB > 6 ? MAXKB - 6 : 0; kb < MAXKB; ++kb)
-      if ((kb + 1) * 16 > T) {                // wave-uniform: only key blocks that reach past T are touched
+      if ((kb + 1) * 16 > Tk) {               // wave-uniform: only key blocks that reach past the last key are touched
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                                int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                                SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok,
-                                                               int pad_idx) {
+                                                               int pad_idx, const bf16_t* __restrict__ bias_kv) {
   constexpr int MAXKB = 18, tpad = MAXKB * 16, nkc = MAXKB / 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128];
   char* Ks = smem;
@@ -296,8 +302,9 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
   for (int db = 0; db < 4; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m = -3.0e38f, l = 0.f;
   constexpr float LOG2E = 1.44269504088896341f;
+  const int Tk = T + (bias_kv ? 1 : 0);              // ESM-1: key T = this head's bias_k / bias_v (see attention_kernel)
 
-  for (int k0 = 0; k0 < T; k0 += tpad) {
+  for (int k0 = 0; k0 < Tk; k0 += tpad) {
     __syncthreads();
     {   // stage this key tile: K and V rows, swizzled (as in attention_kernel)
       constexpr int NIT = (tpad * 8 + 255) / 256;
@@ -310,6 +317,9 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
         if (i < tpad * 8 && k0 + row < T) {
           kreg[it] = *(const uint4*)(base + (size_t)(k0 + row) * ld_qkv + k_off + c * 8);
           vreg[it] = *(const uint4*)(base + (size_t)(k0 + row) * ld_qkv + v_off + c * 8);
+        } else if (bias_kv && k0 + row == T) {
+          kreg[it] = *(const uint4*)(bias_kv + h * 64 + c * 8);
+          vreg[it] = *(const uint4*)(bias_kv + (H + h) * 64 + c * 8);
         }
       }
 #pragma unroll
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
       }
     }
     float tmax = -3.0e38f;
-    const int tl = T - k0 - fq * 4;              // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
+    const int tl = Tk - k0 - fq * 4;             // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
 #pragma unroll
     for (int kb = 0; kb < MAXKB; ++kb)
 #pragma unroll
@@ -413,21 +423,23 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
 }
 
 int launch_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int B, int T, int H, int ld_qkv, int ld_ctx,
-                          int k_off, int v_off, const int32_t* key_tok, int pad_idx) {
+                          int k_off, int v_off, const int32_t* key_tok, int pad_idx, const bf16_t* bias_kv) {
   SeqLayout sl = {1, T, 0, 1};
-  return launch_attention_seq_bf16(s, qkv, ctx, B, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx);
+  return launch_attention_seq_bf16(s, qkv, ctx, B, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv);
 }
 
 int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int64_t n_seq, int T, int H, int ld_qkv,
-                              int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx) {
+                              int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx,
+                              const bf16_t* bias_kv) {
   if (n_seq == 0) return 0;
   if (n_seq * H > 0x7fffffff) return fail(1, "attention: too many sequences");
   dim3 grid((unsigned)(n_seq * H)), block(256);
 #define PG_ATT(KB)                                                                                             \
-  else if (T <= KB * 16) {                                                                                     \
-    if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx); \
-    else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx); \
+  else if (Tk <= KB * 16) {                                                                                    \
+    if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
   }
+  const int Tk = T + (bias_kv ? 1 : 0);          // keys: the T tokens + ESM-1's bias_k / bias_v
   if (T <= 0) return fail(1, "attention: empty sequence");
   PG_ATT(2) PG_ATT(4) PG_ATT(8) PG_ATT(12) PG_ATT(18) PG_ATT(24) PG_ATT(30) PG_ATT(36)
 #undef PG_ATT
@@ -435,7 +447,7 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
     const int n_qchunk = (T + 63) / 64;
     if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
     hipLaunchKernelGGL(attention_long_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), block, 0, s, qkv, ctx, T, H, ld_qkv,
-                       ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx);
+                       ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx, bias_kv);
   }
   PG_HIP(hipGetLastError());
   return 0;

@@ -62,7 +62,9 @@ struct SplitAttn {
 
   // rows 0 .. tpad-1 of 64 fp32 at src + row*ld (rows >= n_valid read as zero) -> (hi, lo) bf16 tiles; a tile row is
   // 128 B with its 16-B chunks XOR-swizzled: row*128 + ((c ^ (row & 7)) << 4).  All global loads in flight first.
-  static __device__ __forceinline__ void stage(const float* __restrict__ src, size_t ld, int n_valid, char* Xh, char* Xl, int tid) {
+  // extra (optional): 64 fp32 that stand in for row n_valid (ESM-1: the head's bias_k / bias_v behind the last token)
+  static __device__ __forceinline__ void stage(const float* __restrict__ src, size_t ld, int n_valid, char* Xh, char* Xl, int tid,
+                                               const float* __restrict__ extra = nullptr) {
     constexpr int NIT = (tpad * 8 + 255) / 256;      // one item = 8 d of one key
     float4 r0[NIT], r1[NIT];
 #pragma unroll
@@ -72,6 +74,10 @@ struct SplitAttn {
       r1[it] = r0[it];
       if (i < tpad * 8 && row < n_valid) {
         const float4* p = (const float4*)(src + (size_t)row * ld + c * 8);
+        r0[it] = p[0];
+        r1[it] = p[1];
+      } else if (extra && row == n_valid && i < tpad * 8) {
+        const float4* p = (const float4*)(extra + c * 8);
         r0[it] = p[0];
         r1[it] = p[1];
       }
@@ -210,7 +216,7 @@ struct SplitAttn {
 template <int MAXKB, int NQB>
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(
     const float* __restrict__ qkv, bf16_t* __restrict__ ctx, int split_d, int T, int H, int ld_qkv_, int ld_ctx_, int k_off,
-    int v_off, SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok, int pad_idx) {
+    int v_off, SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok, int pad_idx, const float* __restrict__ bias_kv) {
   using A = SplitAttn<MAXKB>;
   constexpr int tpad = A::tpad;
   __shared__ __attribute__((aligned(16))) char smem[4 * tpad * 128];
@@ -233,12 +239,16 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
     l[j] = 0.f;
   }
 
-  for (int k0 = 0; k0 < T; k0 += tpad) {
+  // ESM-1 (add_bias_kv): key T = this head's bias_k / bias_v -- one more key, never masked (attention.hip)
+  const int Tk = T + (bias_kv ? 1 : 0);
+  const float* bk = bias_kv ? bias_kv + h * 64 : nullptr;
+  const float* bv = bias_kv ? bias_kv + (H + h) * 64 : nullptr;
+  for (int k0 = 0; k0 < Tk; k0 += tpad) {
     __syncthreads();
-    A::stage(base + (size_t)k0 * ld_qkv + k_off, ld_qkv, T - k0, Kh, Kl, tid);
-    A::stage(base + (size_t)k0 * ld_qkv + v_off, ld_qkv, T - k0, Vh, Vl, tid);
+    A::stage(base + (size_t)k0 * ld_qkv + k_off, ld_qkv, T - k0, Kh, Kl, tid, bk);
+    A::stage(base + (size_t)k0 * ld_qkv + v_off, ld_qkv, T - k0, Vh, Vl, tid, bv);
     __syncthreads();
-    const int tl = T - k0 - fq * 4;              // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
+    const int tl = Tk - k0 - fq * 4;             // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
 #pragma unroll
     for (int j = 0; j < NQB; ++j) {
       const int q0 = qbase + j * 64;
@@ -569,9 +579,11 @@ int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores,
 }
 
 int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split_d, int64_t n_seq, int T, int H,
-                         int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx) {
+                         int ld_qkv, int ld_ctx, int k_off, int v_off, SeqLayout sl, const int32_t* key_tok, int pad_idx,
+                         const float* bias_kv) {
   if (n_seq == 0) return 0;
   if (T <= 0) return fail(1, "attention: empty sequence");
+  if (bias_kv && attn_f32_mode() < 0) return fail(1, "attention: the all-VALU cross-check kernel has no bias_k / bias_v key (ESM-1)");
   const int mode = attn_f32_mode();
   // 16-query blocks per wave of the split kernel (its workgroup = 64 * nqb queries, all of them against each staged K / V tile):
   // the smallest of 1, 2, 3, 5 that covers the sequence with one workgroup, else 5 (PGIBBS_ATTN_F32_NQB overrides: A/B runs)
@@ -579,7 +591,7 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
   const int blocks = (T + 15) / 16;
   int nqb = blocks <= 4 ? 1 : (blocks <= 8 ? 2 : (blocks <= 12 ? 3 : 5));
   if (nqb_env == 1 || nqb_env == 2 || nqb_env == 3 || nqb_env == 5) nqb = nqb_env;
-  if (mode < 0 || T <= 64) nqb = 1;
+  if (mode < 0 || T < 64 || (T == 64 && !bias_kv)) nqb = 1;
   const int n_qchunk = (T + 64 * nqb - 1) / (64 * nqb);
   if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
   const dim3 grid((unsigned)(n_seq * H * n_qchunk));
@@ -591,8 +603,8 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
     // tile with one workgroup per CU was 1.6x slower)
 #define PG_ATT_SPLIT(KB, NQ)                                                                                                  \
   hipLaunchKernelGGL((attention_split_kernel<KB, NQ>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
-                     n_qchunk, key_tok, pad_idx)
-    if (T <= 64) PG_ATT_SPLIT(4, 1);
+                     n_qchunk, key_tok, pad_idx, bias_kv)
+    if (T < 64 || (T == 64 && !bias_kv)) PG_ATT_SPLIT(4, 1);
     else if (nqb == 1) PG_ATT_SPLIT(10, 1);
     else if (nqb == 2) PG_ATT_SPLIT(10, 2);
     else if (nqb == 3) PG_ATT_SPLIT(10, 3);

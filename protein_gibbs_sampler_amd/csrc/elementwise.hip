@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
                                                       float* __restrict__ x, int64_t n_tok, int T, int d, int pad_idx,
                                                       int mask_idx, int token_dropout, int rows_per_msa, float eps,
                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2,
-                                                      bf16_t* __restrict__ h2) {
+                                                      bf16_t* __restrict__ h2, float embed_scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_tok) return;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
   n_nonpad = wave_sum_i(n_nonpad);
   n_before = wave_sum_i(n_before);
   const bool is_pad = (tok == pad_idx);
-  float scale = 1.0f;
+  float scale = embed_scale;               // 1 (ESM-1b, MSA-1b); sqrt(d) for ESM-1
   if (token_dropout) {
     scale = (1.0f - 0.15f * 0.8f) / (1.0f - (float)n_mask / (float)n_nonpad);
     if (tok == mask_idx) scale = 0.0f;
@@ -311,11 +311,11 @@ static inline unsigned rows_grid(int64_t rows) { return (unsigned)((rows + 3) / 
 int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, const float* pos, const float* msa_pos,
                     const float* gamma, const float* beta, float* x, int64_t n_tok, int T, int d, int pad_idx,
                     int mask_idx, int token_dropout, int rows_per_msa, float eps, const float* gamma2, const float* beta2,
-                    bf16_t* h2) {
+                    bf16_t* h2, float embed_scale) {
   if (d % 4 || d > kMaxCh * 256) return fail(1, "embed: d must be a multiple of 4 and <= 2048");
   if (n_tok == 0) return 0;
   hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(n_tok)), dim3(256), 0, s, tokens, embed, pos, msa_pos, gamma, beta, x,
-                     n_tok, T, d, pad_idx, mask_idx, token_dropout, rows_per_msa, eps, gamma2, beta2, h2);
+                     n_tok, T, d, pad_idx, mask_idx, token_dropout, rows_per_msa, eps, gamma2, beta2, h2, embed_scale);
   PG_HIP(hipGetLastError());
   return 0;
 }

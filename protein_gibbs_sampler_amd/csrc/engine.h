@@ -41,6 +41,8 @@ struct LnW { float* g = nullptr; float* b = nullptr; };
 struct EsmLayer {
   LnW ln1, ln2;
   DenseW qkv, out, fc1, fc2;
+  bf16_t* bias_kv16 = nullptr;   // ESM-1 (add_bias_kv): [bias_k | bias_v] as 16-bit operands of the engine's flavour ...
+  float* bias_kv32 = nullptr;    // ... and fp32 (strict mode)
 };
 struct MsaLayer {
   LnW ln_row, ln_col, ln_ffn;
@@ -55,7 +57,8 @@ struct Engine {
   std::vector<void*> owned;   // every hipMalloc'd weight block
 
   // weights
-  float *embed = nullptr, *pos = nullptr, *msa_pos = nullptr;
+  float *embed = nullptr, *pos = nullptr, *msa_pos = nullptr, *embed_out = nullptr;
+  float embed_scale() const { return cfg.arch == PG_ARCH_ESM1 ? sqrtf((float)cfg.d_model) : 1.0f; }
   LnW ln_before, ln_after, head_ln;
   DenseW head_dense;
   float* head_bias = nullptr;
@@ -87,6 +90,7 @@ struct Engine {
   // row-attention scores (also the bf16 mode's wide-alignment fallback)
   DevBuf ffn_f32, scores;
   bool strict() const { return precision == PG_PREC_FP32; }
+  bool esm1() const { return cfg.arch == PG_ARCH_ESM1; }      // ESM-1 differences: see pgibbs.h PG_ARCH_ESM1
   // out[Mp][N] fp32 (=|+=) X.W^T + b with X = xh + xl, W = wh + wl as ONE bf16 GEMM over K' = 3K:
   // [xl | xh | xh] . [wh | wl | wh]^T = xl.wh + xh.wl + xh.wh  (the dropped xl.wl term is ~2^-17 relative)
   int dense3(const bf16_t* x3, const DenseW& W, float* out, int Mp, bool accumulate);

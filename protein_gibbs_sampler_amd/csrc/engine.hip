@@ -157,6 +157,25 @@ struct Uploader {
     out.K = K;
     return true;
   }
+  // ESM-1's add_bias_kv: [bias_k | bias_v] as fp32 (strict mode) and as 16-bit operands of the engine's flavour
+  bool bias_kv(EsmLayer& L, const std::string& kname, const std::string& vname, int d) {
+    const float* bk = tm->get(kname, d, err);
+    const float* bv = bk ? tm->get(vname, d, err) : nullptr;
+    if (!bk || !bv) return false;
+    void *d32 = nullptr, *d16 = nullptr;
+    if (hipMalloc(&d32, (size_t)2 * d * 4) != hipSuccess || hipMalloc(&d16, (size_t)2 * d * 2) != hipSuccess) { err = "hipMalloc failed for " + kname; return false; }
+    e->owned.push_back(d32);
+    e->owned.push_back(d16);
+    bool ok = hipMemcpy(d32, bk, (size_t)d * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy((float*)d32 + d, bv, (size_t)d * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && (e->precision == PG_PREC_F16 ? opf16::launch_f32_to_bf16(e->stream, (const float*)d32, (bf16_t*)d16, 2 * d, 1.f)
+                                           : opbf16::launch_f32_to_bf16(e->stream, (const float*)d32, (bf16_t*)d16, 2 * d, 1.f)) == 0;
+    ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
+    if (!ok) { err = "upload failed for " + kname; return false; }
+    L.bias_kv32 = (float*)d32;
+    L.bias_kv16 = (bf16_t*)d16;
+    return true;
+  }
   bool ln(LnW& out, const std::string& prefix, int d) {
     out.g = f32(prefix + ".weight", d);
     out.b = out.g ? f32(prefix + ".bias", d) : nullptr;
@@ -169,7 +188,7 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
   cfg = *c;
   precision = prec;
   device = -1;
-  if (cfg.arch != PG_ARCH_ESM1B && cfg.arch != PG_ARCH_MSA1B) return fail(PG_ERR_INVALID, "unknown arch");
+  if (cfg.arch != PG_ARCH_ESM1B && cfg.arch != PG_ARCH_MSA1B && cfg.arch != PG_ARCH_ESM1) return fail(PG_ERR_INVALID, "unknown arch");
   if (prec != PG_PREC_BF16 && prec != PG_PREC_FP32 && prec != PG_PREC_F16) return fail(PG_ERR_INVALID, "unknown precision mode");
   if (cfg.d_model % 128 || cfg.d_ffn % 128 || cfg.n_heads * 64 != cfg.d_model)
     return fail(PG_ERR_INVALID, "d_model and d_ffn must be multiples of 128 and head dim must be 64");
@@ -192,12 +211,18 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
   bool ok = true;
   ok = ok && (embed = up.f32("embed_tokens.weight", (int64_t)V * d));
   ok = ok && (pos = up.f32("embed_positions.weight", (int64_t)(cfg.max_positions + cfg.pad_idx + 1) * d));
-  ok = ok && up.ln(ln_before, "emb_layer_norm_before", d);
-  ok = ok && up.ln(ln_after, "emb_layer_norm_after", d);
-  ok = ok && up.dense(head_dense, {"lm_head.dense"}, {1.0f}, d, d);
-  ok = ok && up.ln(head_ln, "lm_head.layer_norm", d);
-  ok = ok && (head_bias = up.f32("lm_head.bias", V));
-  if (ok && cfg.arch == PG_ARCH_ESM1B) {
+  if (esm1()) {
+    // untied output projection straight from the residual stream: logits = x embed_out^T + embed_out_bias
+    ok = ok && (embed_out = up.f32("embed_out.weight", (int64_t)V * d));
+    ok = ok && (head_bias = up.f32("embed_out.bias", V));
+  } else {
+    ok = ok && up.ln(ln_before, "emb_layer_norm_before", d);
+    ok = ok && up.ln(ln_after, "emb_layer_norm_after", d);
+    ok = ok && up.dense(head_dense, {"lm_head.dense"}, {1.0f}, d, d);
+    ok = ok && up.ln(head_ln, "lm_head.layer_norm", d);
+    ok = ok && (head_bias = up.f32("lm_head.bias", V));
+  }
+  if (ok && cfg.arch != PG_ARCH_MSA1B) {
     esm_layers.resize(cfg.n_layers);
     for (int i = 0; ok && i < cfg.n_layers; ++i) {
       const std::string p = "layers." + std::to_string(i) + ".";
@@ -208,6 +233,7 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
       ok = ok && up.ln(L.ln2, p + "final_layer_norm", d);
       ok = ok && up.dense(L.fc1, {p + "fc1"}, {1.f}, f, d);
       ok = ok && up.dense(L.fc2, {p + "fc2"}, {1.f}, d, f);
+      if (ok && esm1()) ok = up.bias_kv(L, p + "self_attn.bias_k", p + "self_attn.bias_v", d);
     }
   } else if (ok) {
     ok = ok && (msa_pos = up.f32("msa_position_embedding", (int64_t)cfg.max_msa_rows * d));
@@ -290,7 +316,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     const int Mi = (int)Mp;
     rc = timed(PC_EMBED, [&] {
       return OPS(launch_embed_ln, stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
-                             cfg.mask_idx, cfg.token_dropout, 0, eps);
+                             cfg.mask_idx, cfg.token_dropout, 0, eps, nullptr, nullptr, nullptr, embed_scale());
     });
     if (rc) return rc;
     const SeqLayout chain = {1, T, 0, 1};
@@ -298,7 +324,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
       const EsmLayer& L = esm_layers[l];
       if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
       if ((rc = dense3(h.as<bf16_t>(), L.qkv, QKVf, Mi, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), d, B, T, cfg.n_heads, 3 * d, 3 * d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), d, B, T, cfg.n_heads, 3 * d, 3 * d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx, L.bias_kv32); }))) return rc;
       if ((rc = dense3(ctx.as<bf16_t>(), L.out, X, Mi, true))) return rc;
       if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
       if ((rc = dense3_gelu(h.as<bf16_t>(), L.fc1, Mi))) return rc;
@@ -328,7 +354,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   rc = timed(PC_EMBED, [&] {
     return OPS(launch_embed_ln, stream, d_tok, embed, pos, nullptr, ln_before.g, ln_before.b, X, M, T, d, cfg.pad_idx,
                            cfg.mask_idx, cfg.token_dropout, 0, eps, ln_in_gemm ? nullptr : esm_layers[0].ln1.g,
-                           ln_in_gemm ? nullptr : esm_layers[0].ln1.b, ln_in_gemm ? nullptr : Hh);
+                           ln_in_gemm ? nullptr : esm_layers[0].ln1.b, ln_in_gemm ? nullptr : Hh, embed_scale());
   });
   if (rc) return rc;
   for (int l = 0; l < cfg.n_layers; ++l) {
@@ -339,7 +365,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     } else {
       if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     }
-    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_bf16, stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_bf16, stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx, L.bias_kv16); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: only the selected rows are ever read again -> gather them and finish the layer on n_sel rows
       const int64_t Np = round_up64(n_sel, kRowPad);
@@ -399,6 +425,17 @@ int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int wid
   const int d = cfg.d_model, V = cfg.vocab;
   const int64_t Np = round_up64(n_sel, kRowPad);
   int rc;
+  if (esm1()) {
+    // ESM-1: logits = x embed_out^T + embed_out_bias on the selected rows of the residual stream (no final LayerNorm, no dense);
+    // the decoder kernel with its LayerNorm switched off (gamma == nullptr), fp32 throughout in every precision mode
+    const float* rows = x_src;
+    if (d_idx_) {
+      if ((rc = sel_g.ensure((size_t)Np * d * 4, stream))) return rc;
+      if ((rc = launch_gather_rows(stream, x_src, sel_g.as<float>(), d_idx_, d_row_map, P, width, n_sel, d * 4))) return rc;
+      rows = sel_g.as<float>();
+    }
+    return timed(PC_HEAD, [&] { return launch_lm_tail(stream, rows, nullptr, nullptr, embed_out, head_bias, d_logits, n_sel, d, V, cfg.layer_norm_eps); });
+  }
   if ((rc = sel_h.ensure((size_t)Np * d * 2, stream))) return rc;
   if ((rc = sel_g.ensure((size_t)Np * d * 4, stream))) return rc;
   const float eps = cfg.layer_norm_eps;
@@ -423,7 +460,7 @@ int Engine::head(const int32_t* d_idx_, const int32_t* d_row_map, int P, int wid
 
 int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_, int n_iters, int P,
                              const pg_sample_params* sp, float* d_samp_logits_, int32_t* d_samp_tok_) {
-  if (cfg.arch != PG_ARCH_ESM1B) return fail(PG_ERR_INVALID, "engine was not built for the ESM-1b architecture");
+  if (cfg.arch != PG_ARCH_ESM1B && cfg.arch != PG_ARCH_ESM1) return fail(PG_ERR_INVALID, "engine was not built for an ESM-1b / ESM-1 architecture");
   if (B < 0 || T < 1 || P < 0 || n_iters < 0) return fail(PG_ERR_INVALID, "gibbs: negative size");
   if (T > cfg.max_positions) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
   if (B == 0 || n_iters == 0) return PG_OK;

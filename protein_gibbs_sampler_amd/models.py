@@ -60,14 +60,25 @@ class ESM_MSA1(_Wrapper):
                          "esm_msa1b_t12_100M_UR50S.pt", seed, precision, synthetic)
 
 
-def _esm1_unsupported(name):
-    def ctor(*a, **k):
-        raise NotImplementedError(
-            name + " is an ESM-1 (sinusoidal positions, no token dropout) model; this engine implements the "
-            "ESM-1b and ESM-MSA-1b architectures that the Gibbs hot path is benchmarked on")
-    return ctor
+class _ESM1(_Wrapper):
+    """ESM-1 family (models.py:69-82): the 35-token "ESM-1" alphabet, <cls> prepended, no <eos>."""
+    _cfg, _file = None, None
+
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
+        super().__init__(config or dict(self._cfg), Alphabet(True, False, arch="ESM-1"), False, state_dict, checkpoint,
+                         self._file, seed, precision, synthetic)
 
 
-ESM6 = _esm1_unsupported("esm1_t6_43M_UR50S")
-ESM12 = _esm1_unsupported("esm1_t12_85M_UR50S")
-ESM34 = _esm1_unsupported("esm1_t34_670M_UR50S")
+class ESM6(_ESM1):
+    """esm1_t6_43M_UR50S (models.py:69-72): the model the reference's own unit tests load (test/test_esm_sampler.py:10-18)."""
+    _cfg, _file = _w.ESM1_T6_CONFIG, "esm1_t6_43M_UR50S.pt"
+
+
+class ESM12(_ESM1):
+    """esm1_t12_85M_UR50S (models.py:74-77)."""
+    _cfg, _file = _w.ESM1_T12_CONFIG, "esm1_t12_85M_UR50S.pt"
+
+
+class ESM34(_ESM1):
+    """esm1_t34_670M_UR50S (models.py:79-82)."""
+    _cfg, _file = _w.ESM1_T34_CONFIG, "esm1_t34_670M_UR50S.pt"

@@ -20,6 +20,29 @@ MSA1B_CONFIG = dict(arch=_lib.PG_ARCH_MSA1B, vocab=33, d_model=768, n_layers=12,
                     pad_idx=1, mask_idx=32, cls_idx=0, eos_idx=2, token_dropout=0, max_msa_rows=1024, layer_norm_eps=1e-5)
 
 
+# ESM-1 (fair-esm "protein_bert_base": esm1_t6_43M / t12_85M / t34_670M_UR50S -- pgen.models.ESM6 / ESM12 / ESM34): sqrt(d) embedding
+# scale, sinusoidal positions, no emb_layer_norm_before / after, bias_k / bias_v, LayerNorm eps 1e-12, untied embed_out, no token
+# dropout, the 35-token "ESM-1" alphabet (include/pgibbs.h PG_ARCH_ESM1)
+ESM1_T6_CONFIG = dict(arch=_lib.PG_ARCH_ESM1, vocab=35, d_model=768, n_layers=6, n_heads=12, d_ffn=3072, max_positions=1024,
+                      pad_idx=1, mask_idx=33, cls_idx=32, eos_idx=2, token_dropout=0, max_msa_rows=0, layer_norm_eps=1e-12)
+ESM1_T12_CONFIG = dict(ESM1_T6_CONFIG, n_layers=12)
+ESM1_T34_CONFIG = dict(ESM1_T6_CONFIG, n_layers=34, d_model=1280, n_heads=20, d_ffn=5120)
+
+
+def sinusoidal_positions(n_rows, d, pad_idx):
+    """fairseq / fair-esm SinusoidalPositionalEmbedding.get_embedding in float32 ([sin | cos] halves, inv_freq =
+    exp(-i log(10000) / (d/2 - 1)), padding row zero): the engine reads it as its `embed_positions.weight` table."""
+    half = d // 2
+    step = np.float32(np.log(10000.0) / (half - 1))
+    inv = np.exp(np.arange(half, dtype=np.float32) * -step).astype(np.float32)
+    ang = (np.arange(n_rows, dtype=np.float32)[:, None] * inv[None, :]).astype(np.float32)
+    emb = np.concatenate([np.sin(ang), np.cos(ang)], axis=1).astype(np.float32)
+    if d % 2:
+        emb = np.concatenate([emb, np.zeros((n_rows, 1), np.float32)], axis=1)
+    emb[pad_idx] = 0
+    return emb
+
+
 def make_config(base, **overrides):
     cfg = dict(base)
     cfg.update(overrides)
@@ -31,12 +54,16 @@ def make_config(base, **overrides):
 def tensor_shapes(cfg):
     """name -> shape for every tensor the engine reads (fair-esm state-dict keys)."""
     d, f, V = cfg["d_model"], cfg["d_ffn"], cfg["vocab"]
-    s = {"embed_tokens.weight": (V, d),
-         "embed_positions.weight": (cfg["max_positions"] + cfg["pad_idx"] + 1, d),
-         "emb_layer_norm_before.weight": (d,), "emb_layer_norm_before.bias": (d,),
-         "emb_layer_norm_after.weight": (d,), "emb_layer_norm_after.bias": (d,),
-         "lm_head.dense.weight": (d, d), "lm_head.dense.bias": (d,),
-         "lm_head.layer_norm.weight": (d,), "lm_head.layer_norm.bias": (d,), "lm_head.bias": (V,)}
+    if cfg["arch"] == _lib.PG_ARCH_ESM1:
+        s = {"embed_tokens.weight": (V, d), "embed_positions.weight": (cfg["max_positions"] + cfg["pad_idx"] + 1, d),
+             "embed_out.weight": (V, d), "embed_out.bias": (V,)}
+    else:
+        s = {"embed_tokens.weight": (V, d),
+             "embed_positions.weight": (cfg["max_positions"] + cfg["pad_idx"] + 1, d),
+             "emb_layer_norm_before.weight": (d,), "emb_layer_norm_before.bias": (d,),
+             "emb_layer_norm_after.weight": (d,), "emb_layer_norm_after.bias": (d,),
+             "lm_head.dense.weight": (d, d), "lm_head.dense.bias": (d,),
+             "lm_head.layer_norm.weight": (d,), "lm_head.layer_norm.bias": (d,), "lm_head.bias": (V,)}
 
     def lin(p, o, i):
         s[p + ".weight"] = (o, i)
@@ -48,9 +75,12 @@ def tensor_shapes(cfg):
 
     for i in range(cfg["n_layers"]):
         p = "layers.%d." % i
-        if cfg["arch"] == _lib.PG_ARCH_ESM1B:
+        if cfg["arch"] in (_lib.PG_ARCH_ESM1B, _lib.PG_ARCH_ESM1):
             for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
                 lin(p + "self_attn." + n, d, d)
+            if cfg["arch"] == _lib.PG_ARCH_ESM1:
+                s[p + "self_attn.bias_k"] = (d,)
+                s[p + "self_attn.bias_v"] = (d,)
             ln(p + "self_attn_layer_norm")
             lin(p + "fc1", f, d)
             lin(p + "fc2", d, f)
@@ -79,8 +109,12 @@ def synthetic_state_dict(cfg, seed=0, std=0.02, embed_std=None, ln_jitter=0.0):
             a = 1.0 + ln_jitter * rng.standard_normal(shape, dtype=np.float32)
         elif is_ln:
             a = ln_jitter * rng.standard_normal(shape, dtype=np.float32)
+        elif name == "embed_positions.weight" and cfg["arch"] == _lib.PG_ARCH_ESM1:
+            a = sinusoidal_positions(shape[0], shape[1], cfg["pad_idx"])
         elif name.startswith("embed_") or name == "msa_position_embedding":
             a = es * rng.standard_normal(shape, dtype=np.float32)
+        elif name.endswith("bias_k") or name.endswith("bias_v"):
+            a = 0.3 * rng.standard_normal(shape, dtype=np.float32)
         else:
             a = std * rng.standard_normal(shape, dtype=np.float32)
         out[name] = np.ascontiguousarray(a, dtype=np.float32)
@@ -94,6 +128,8 @@ def _strip_fair_esm_prefixes(name):
     for marker in ("sentence_encoder.", "encoder."):
         if marker in name:
             name = name.split(marker, 1)[1]
+    if name.startswith("decoder."):            # ESM-1 ("protein_bert_base") checkpoints: everything under `decoder.`
+        name = name[len("decoder."):]
     return name[len("model."):] if name.startswith("model.") else name
 
 
@@ -124,8 +160,18 @@ def normalise_state_dict(sd, cfg, fair_esm_layout=True):
             if is_msa:
                 name = _swap_row_column(name)
         arr = v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, dtype=np.float32)
+        if cfg["arch"] == _lib.PG_ARCH_ESM1:
+            # fair-esm's ESM-1 module names -> the engine's: the untied output projection is a bare Parameter pair, bias_k / bias_v
+            # are stored [1, 1, d]; the sinusoidal table is a buffer (`embed_positions._float_tensor`) that is regenerated here
+            name = {"embed_out": "embed_out.weight", "embed_out_bias": "embed_out.bias"}.get(name, name)
+            if name.endswith("self_attn.bias_k") or name.endswith("self_attn.bias_v"):
+                arr = arr.reshape(-1)
         named[name] = arr
-    if "lm_head.weight" in named:
+    if cfg["arch"] == _lib.PG_ARCH_ESM1 and "embed_positions.weight" not in named:
+        named["embed_positions.weight"] = sinusoidal_positions(cfg["max_positions"] + cfg["pad_idx"] + 1, cfg["d_model"], cfg["pad_idx"])
+    if cfg["arch"] == _lib.PG_ARCH_ESM1 and "embed_out.bias" not in named and "embed_out.weight" in named:
+        named["embed_out.bias"] = np.zeros(cfg["vocab"], dtype=np.float32)          # final_bias = False checkpoints
+    if "lm_head.weight" in named and cfg["arch"] != _lib.PG_ARCH_ESM1:
         if "embed_tokens.weight" not in named:
             named["embed_tokens.weight"] = named["lm_head.weight"]
         elif not np.array_equal(named["lm_head.weight"], named["embed_tokens.weight"]):
@@ -167,6 +213,9 @@ def load_fair_esm_checkpoint(path, cfg):
     want_msa = cfg["arch"] == _lib.PG_ARCH_MSA1B
     if arch is not None and (arch == "msa_transformer") != want_msa:
         raise ValueError("checkpoint arch %r does not match the requested %s engine" % (arch, "MSA-1b" if want_msa else "ESM-1b"))
+    if arch is not None and (arch == "protein_bert_base") != (cfg["arch"] == _lib.PG_ARCH_ESM1):
+        raise ValueError("checkpoint arch %r does not match the requested %s engine"
+                         % (arch, "ESM-1" if cfg["arch"] == _lib.PG_ARCH_ESM1 else "ESM-1b / MSA-1b"))
     return normalise_state_dict(sd, cfg, fair_esm_layout=True)
 
 

@@ -315,3 +315,42 @@ def test_loader_against_the_literal_checkpoint_key_list(which, tmp_path):
         assert not np.array_equal(got["layers.1.row_self_attention.layer.q_proj.weight"], on_disk_row)
     else:
         assert (got["embed_tokens.weight"][small["mask_idx"]] == 0).all()      # fair-esm zeroes the <mask> row of ESM-1b checkpoints
+
+
+def test_esm1_alphabet_and_checkpoint_layout(tmp_path):
+    """ESM-1 family (pgen.models.ESM6 / 12 / 34): the 35-token alphabet as the reference's tests see it (test_esm_sampler.py:43-60:
+    <cls> = 32, A = 5, <mask> = 33) and a "protein_bert_base" checkpoint file -- everything under `decoder.`, the untied output
+    projection as bare `embed_out` / `embed_out_bias`, bias_k / bias_v stored [1, 1, d], the sinusoidal table as a buffer."""
+    import argparse
+    import torch
+    from protein_gibbs_sampler_amd import weights
+    from protein_gibbs_sampler_amd.alphabet import Alphabet
+    a = Alphabet(True, False, arch="ESM-1")
+    assert (len(a), a.cls_idx, a.mask_idx, a.padding_idx, a.eos_idx, a.get_idx("A"), a.get_idx("<sep>")) == (35, 32, 33, 1, 2, 5, 34)
+    assert a.get_batch_converter()([("0", "AA<mask><mask><mask>")])[2].tolist() == [[32, 5, 5, 33, 33, 33]]
+    cfg = weights.make_config(weights.ESM1_T6_CONFIG, d_model=128, n_layers=2, d_ffn=256, max_positions=64)
+    sd = weights.synthetic_state_dict(cfg, seed=4)
+    disk = {}
+    for k, v in sd.items():
+        if k == "embed_positions.weight":
+            disk["decoder.embed_positions._float_tensor"] = torch.zeros(1)
+        elif k == "embed_out.weight":
+            disk["decoder.embed_out"] = torch.from_numpy(v)
+        elif k == "embed_out.bias":
+            disk["decoder.embed_out_bias"] = torch.from_numpy(v)
+        elif k.endswith("bias_k") or k.endswith("bias_v"):
+            disk["decoder." + k] = torch.from_numpy(v).view(1, 1, -1)
+        else:
+            disk["decoder." + k] = torch.from_numpy(v)
+    path = tmp_path / "esm1.pt"
+    torch.save({"model": disk, "args": argparse.Namespace(arch="protein_bert_base")}, path)
+    got = weights.load_fair_esm_checkpoint(str(path), cfg)
+    assert set(got) == set(sd)
+    for k in sd:
+        assert np.array_equal(got[k], sd[k]), k                      # incl. the regenerated sinusoidal table
+    with pytest.raises(ValueError):
+        weights.load_fair_esm_checkpoint(str(path), weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=2, d_ffn=256, max_positions=64))
+    # the sinusoidal table: position 0 = [0.. | 1..], padding row zero, last frequency 1 / 10000
+    t = weights.sinusoidal_positions(10, 128, 1)
+    assert (t[1] == 0).all() and np.allclose(t[0, :64], 0) and np.allclose(t[0, 64:], 1)
+    assert abs(t[5, 63] - np.sin(5e-4)) < 1e-6
