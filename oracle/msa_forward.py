@@ -54,8 +54,11 @@ def msa_embed(w, cfg, tokens):
     return np.where(pad[..., None], F32(0), x).astype(F32)
 
 
-def row_attention(w, p, cfg, h):
-    """Tied row attention: one C x C map per head shared by all rows of an MSA."""
+def row_attention(w, p, cfg, h, pad=None):
+    """Tied row attention: one C x C map per head shared by all rows of an MSA.
+    pad (bool [B,R,C], only when the batch holds <pad>: ragged MSA lists, esm_msa_sampler.py:341) -- fair-esm's RowSelfAttention
+    zeroes q at padded positions ("we take a sum across the alignment axis") and fills the scores of the key columns that are
+    <pad> in ROW 0 with -10000 (a finite fill, not -inf); the 1/sqrt(R) uses the padded row count."""
     B, R, C, d = h.shape
     H = cfg.n_heads
     dh = d // H
@@ -63,13 +66,18 @@ def row_attention(w, p, cfg, h):
     q = linear(h, w[p + "q_proj.weight"], w[p + "q_proj.bias"]).reshape(B, R, C, H, dh) * scale
     k = linear(h, w[p + "k_proj.weight"], w[p + "k_proj.bias"]).reshape(B, R, C, H, dh)
     v = linear(h, w[p + "v_proj.weight"], w[p + "v_proj.bias"]).reshape(B, R, C, H, dh)
+    if pad is not None:
+        q = np.where(pad[..., None, None], F32(0), q)
     a = np.einsum("brihd,brjhd->bhij", q, k, optimize=True).astype(F32)
+    if pad is not None:
+        a = np.where(pad[:, 0][:, None, None, :], F32(-10000.0), a)
     pr = softmax_lastdim(a)
     ctx = np.einsum("bhij,brjhd->brihd", pr, v, optimize=True).astype(F32).reshape(B, R, C, d)
     return linear(ctx, w[p + "out_proj.weight"], w[p + "out_proj.bias"])
 
 
-def column_attention(w, p, cfg, h):
+def column_attention(w, p, cfg, h, pad=None):
+    """pad: fair-esm's ColumnSelfAttention fills the scores of key rows that are <pad> at that column with -10000."""
     B, R, C, d = h.shape
     H = cfg.n_heads
     dh = d // H
@@ -79,6 +87,8 @@ def column_attention(w, p, cfg, h):
     k = linear(h, w[p + "k_proj.weight"], w[p + "k_proj.bias"]).reshape(B, R, C, H, dh)
     v = linear(h, w[p + "v_proj.weight"], w[p + "v_proj.bias"]).reshape(B, R, C, H, dh)
     a = np.einsum("bichd,bjchd->bhcij", q, k, optimize=True).astype(F32)
+    if pad is not None:
+        a = np.where(pad.transpose(0, 2, 1)[:, None, :, None, :], F32(-10000.0), a)      # [B,1,C,1,R(j)]
     pr = softmax_lastdim(a)
     ctx = np.einsum("bhcij,bjchd->bichd", pr, v, optimize=True).astype(F32).reshape(B, R, C, d)
     return linear(ctx, w[p + "out_proj.weight"], w[p + "out_proj.bias"])
@@ -86,12 +96,14 @@ def column_attention(w, p, cfg, h):
 
 def msa_trunk(w, cfg, tokens):
     x = msa_embed(w, cfg, tokens)
+    pad = np.asarray(tokens) == cfg.pad_idx
+    pad = pad if pad.any() else None              # fair-esm: `if not padding_mask.any(): padding_mask = None`
     for i in range(cfg.n_layers):
         p = "layers.%d." % i
         h = layer_norm(x, w[p + "row_self_attention.layer_norm.weight"], w[p + "row_self_attention.layer_norm.bias"])
-        x = (x + row_attention(w, p + "row_self_attention.layer.", cfg, h)).astype(F32)
+        x = (x + row_attention(w, p + "row_self_attention.layer.", cfg, h, pad)).astype(F32)
         h = layer_norm(x, w[p + "column_self_attention.layer_norm.weight"], w[p + "column_self_attention.layer_norm.bias"])
-        x = (x + column_attention(w, p + "column_self_attention.layer.", cfg, h)).astype(F32)
+        x = (x + column_attention(w, p + "column_self_attention.layer.", cfg, h, pad)).astype(F32)
         h = layer_norm(x, w[p + "feed_forward_layer.layer_norm.weight"], w[p + "feed_forward_layer.layer_norm.bias"])
         h = gelu(linear(h, w[p + "feed_forward_layer.layer.fc1.weight"], w[p + "feed_forward_layer.layer.fc1.bias"]))
         x = (x + linear(h, w[p + "feed_forward_layer.layer.fc2.weight"], w[p + "feed_forward_layer.layer.fc2.bias"])).astype(F32)

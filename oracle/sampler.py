@@ -348,6 +348,29 @@ def msa_log_likelihood_batch(forward, msa_list, target_index=0, with_masking=Tru
     alphabet = Alphabet1b(append_eos=False)
     gap = {alphabet.get_idx("-")}
     out = []
+    if not with_masking:
+        # esm_msa_sampler.py:341, 416-431: the WHOLE list is converted into one tensor padded with <pad> to the deepest / widest
+        # MSA, `batch_size` of them per forward; scores are read from the padded tensor's row `target_index`
+        rows = [alphabet.rows_to_tokens([clean_seed_seq(s, MSA_ALLOWED) for s in msa]) for msa in msa_list]
+        R, C = max(r.shape[0] for r in rows), max(r.shape[1] for r in rows)
+        tokens = np.full((len(rows), R, C), alphabet.padding_idx, dtype=np.int64)
+        for i, r in enumerate(rows):
+            tokens[i, :r.shape[0], :r.shape[1]] = r
+        for b0 in range(0, len(rows), max(1, batch_size)):
+            lp = _log_softmax(forward(tokens[b0:b0 + max(1, batch_size)]))
+            for i in range(lp.shape[0]):
+                msa = msa_list[b0 + i]
+                L = len(msa[target_index])
+                denom = L - (0 if count_gaps else msa[target_index].count("-"))
+                orig = tokens[b0 + i, target_index]
+                total, lst = np.float32(0.0), []
+                for pos in range(1, L + 1):
+                    if count_gaps or int(orig[pos]) not in gap:
+                        v = lp[i, target_index, pos, orig[pos]]
+                        total = np.float32(total + v)
+                        lst.append(float(v))
+                out.append((float(total / np.float32(denom)), lst))
+        return out
     for msa in msa_list:
         one = alphabet.rows_to_tokens([clean_seed_seq(s, MSA_ALLOWED) for s in msa])[None]
         L = len(msa[target_index])

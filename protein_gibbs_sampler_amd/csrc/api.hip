@@ -199,6 +199,9 @@ int pg_msa_forward_logits(pg_engine* h, const int32_t* tokens, int B, int R, int
   if ((rc = e.d_tokens.ensure((size_t)M * 4, e.stream))) return rc;
   if ((rc = e.logits.ensure((size_t)M * e.cfg.vocab * 4, e.stream))) return rc;
   PG_HIP(hipMemcpyAsync(e.d_tokens.p, tokens, (size_t)M * 4, hipMemcpyHostToDevice, e.stream));
+  // a ragged list of MSAs padded to one tensor (esm_msa_sampler.py:341): fair-esm's padding semantics in both attention blocks
+  struct PadFlag { Engine& e; ~PadFlag() { e.esm_pad_in_batch = false; } } pad_reset{e};
+  e.esm_pad_in_batch = has_token(tokens, (size_t)M, e.cfg.pad_idx);
   if ((rc = e.msa_trunk(e.d_tokens.as<int32_t>(), B, R, C))) return rc;
   if ((rc = e.head(nullptr, nullptr, 1, C, M, e.logits.as<float>()))) return rc;
   PG_HIP(hipMemcpyAsync(logits_out, e.logits.p, (size_t)M * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
@@ -345,9 +348,7 @@ static int forward_logprobs(Engine& e, bool msa, const int32_t* tokens, int B, i
   PG_HIP(hipMemcpyAsync(e.d_idx.p, idx, (size_t)n * 4, hipMemcpyHostToDevice, e.stream));
   PG_HIP(hipMemcpyAsync(e.d_samp_tok.p, targets, (size_t)n * 4, hipMemcpyHostToDevice, e.stream));
   PG_HIP(hipMemcpyAsync(e.d_rowmap.p, row_of, (size_t)n_sel * 4, hipMemcpyHostToDevice, e.stream));
-  e.esm_pad_in_batch = false;
-  if (!msa)
-    for (int64_t i = 0; i < M; ++i) e.esm_pad_in_batch |= tokens[i] == e.cfg.pad_idx;
+  e.esm_pad_in_batch = has_token(tokens, (size_t)M, e.cfg.pad_idx);      // ragged batch: <pad> keys masked (both architectures)
   rc = msa ? e.msa_trunk(e.d_tokens.as<int32_t>(), B, R, C) : e.esm_trunk(e.d_tokens.as<int32_t>(), B, C);
   e.esm_pad_in_batch = false;
   if (rc) return rc;

@@ -168,15 +168,21 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][r]);      // -> v_max3_f32
     if (PADMASK) {
       // ragged batch (only reachable through the forward entry points; the Gibbs path never holds <pad>): keys that are
-      // <pad> tokens get -inf like fair-esm's key_padding_mask.  key_tok = the token buffer, sequence `seq` at seq*T.
-      const int32_t* kt = key_tok + (size_t)seq * T;
+      // <pad> tokens are masked.  key_tok = the token buffer; the token of key t of this sequence sits where its qkv row does
+      // (row0 + t * row_step).  Chains (ESM: contiguous rows) get -inf like fair-esm's key_padding_mask; the strided sequences
+      // of the MSA Transformer's column attention get its finite fill of -10000 (an all-<pad> column then softmaxes to a uniform
+      // row instead of NaN, exactly as fair-esm's ColumnSelfAttention does -- and NaN at a padded position would reach the real
+      // ones through 0 * NaN in the next tied row attention).
+      const int32_t* kt = key_tok + row0;
+      const int kstep = sl.row_step;
+      const float fill = kstep == 1 ? -3.0e38f : -10000.0f;
       mx = -3.0e38f;
 #pragma unroll
       for (int kb = 0; kb < MAXKB; ++kb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kb * 16 + fq * 4 + r;
-          if (key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
+          if (key < T && kt[(size_t)key * kstep] == pad_idx) st[kb][r] = fill;
           mx = fmaxf(mx, st[kb][r]);
         }
       }
@@ -354,14 +360,15 @@ __global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __
         tmax = fmaxf(tmax, st[kb][r]);
       }
     if (key_tok) {                               // <pad> keys of a ragged batch (see attention_kernel)
-      const int32_t* kt = key_tok + (size_t)seq * T + k0;
+      const int32_t* kt = key_tok + row0 + (size_t)k0 * sl.row_step;
+      const float fill = sl.row_step == 1 ? -3.0e38f : -10000.0f;
       tmax = -3.0e38f;
 #pragma unroll
       for (int kb = 0; kb < MAXKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kb * 16 + fq * 4 + r;
-          if (k0 + key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
+          if (k0 + key < T && kt[(size_t)key * sl.row_step] == pad_idx) st[kb][r] = fill;
           tmax = fmaxf(tmax, st[kb][r]);
         }
     }

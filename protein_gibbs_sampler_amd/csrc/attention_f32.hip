@@ -264,14 +264,16 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
-      if (key_tok) {                               // <pad> keys of a ragged batch (key_tok = token buffer, sequence seq at seq*T)
-        const int32_t* kt = key_tok + (size_t)seq * T + k0;
+      if (key_tok) {      // <pad> keys of a ragged batch: token of key t at key_tok[row0 + t * row_step]; -inf for chains, fair-esm's
+                          // finite -10000 for the MSA Transformer's column attention (attention.hip)
+        const int32_t* kt = key_tok + row0 + (size_t)k0 * sl.row_step;
+        const float fill = sl.row_step == 1 ? -3.0e38f : -10000.0f;
 #pragma unroll
         for (int kb = 0; kb < MAXKB; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kb * 16 + fq * 4 + r;
-            if (k0 + key < T && kt[key] == pad_idx) st[kb][r] = -3.0e38f;
+            if (k0 + key < T && kt[(size_t)key * sl.row_step] == pad_idx) st[kb][r] = fill;
           }
       }
       A::softmax_pv(st, o[j], m[j], l[j], Vh, Vl, fr, fq);
@@ -290,7 +292,11 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
 template <int MAXKB>
 __global__ __launch_bounds__(256, 2) void msa_row_scores_split_kernel(const float* __restrict__ qkv, float* __restrict__ S, int R,
                                                                       int C, int H, int ld_qkv, int k_off, float scale,
-                                                                      int n_qchunk, int n_ktile, int ldS) {
+                                                                      int n_qchunk, int n_ktile, int ldS,
+                                                                      const int32_t* __restrict__ tok, int pad_idx) {
+  // tok (optional: a ragged list of MSAs padded to one [B][R][C] tensor, esm_msa_sampler.py:341): fair-esm's RowSelfAttention
+  // zeroes q at <pad> positions before the sum over alignment rows and fills the scores of the key columns that are <pad> in
+  // ROW 0 with -10000 (finite; the softmax in the apply kernel sees ordinary numbers)
   using A = SplitAttn<MAXKB>;
   constexpr int tpad = A::tpad;
   __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128];
@@ -310,6 +316,10 @@ __global__ __launch_bounds__(256, 2) void msa_row_scores_split_kernel(const floa
     const float* rb = base + (size_t)r * C * ld_qkv;
     bf16x8 qh[2], ql[2];
     A::load_q(rb + (size_t)qrow * ld_qkv, fq, qh, ql);
+    if (tok && tok[((size_t)b * R + r) * C + qrow] == pad_idx) {
+      const bf16x8 z = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+      qh[0] = z; qh[1] = z; ql[0] = z; ql[1] = z;
+    }
     __syncthreads();
     A::stage(rb + (size_t)k0 * ld_qkv + k_off, ld_qkv, C - k0, Kh, Kl, tid);
     __syncthreads();
@@ -320,8 +330,18 @@ __global__ __launch_bounds__(256, 2) void msa_row_scores_split_kernel(const floa
     float* dst = S + ((size_t)bh * C + q) * ldS + k0 + fq * 4;
 #pragma unroll
     for (int kb = 0; kb < MAXKB; ++kb)
-      if (k0 + kb * 16 + fq * 4 < ldS)
-        *(float4*)(dst + kb * 16) = make_float4(st[kb][0] * scale, st[kb][1] * scale, st[kb][2] * scale, st[kb][3] * scale);
+      if (k0 + kb * 16 + fq * 4 < ldS) {
+        float4 v = make_float4(st[kb][0] * scale, st[kb][1] * scale, st[kb][2] * scale, st[kb][3] * scale);
+        if (tok) {
+          const int32_t* t0 = tok + (size_t)b * R * C;            // row 0 of this MSA
+          const int key = k0 + kb * 16 + fq * 4;
+          if (key < C && t0[key] == pad_idx) v.x = -10000.f;
+          if (key + 1 < C && t0[key + 1] == pad_idx) v.y = -10000.f;
+          if (key + 2 < C && t0[key + 2] == pad_idx) v.z = -10000.f;
+          if (key + 3 < C && t0[key + 3] == pad_idx) v.w = -10000.f;
+        }
+        *(float4*)(dst + kb * 16) = v;
+      }
   }
 }
 
@@ -551,8 +571,10 @@ static int attn_f32_mode() {
 }
 
 int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores, bf16_t* ctx, int split_d, int B, int R,
-                                 int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale) {
+                                 int C, int H, int ld_qkv, int ld_ctx, int k_off, int v_off, float scale, const int32_t* tok,
+                                 int pad_idx) {
   if (B == 0 || R == 0) return 0;
+  if (tok && attn_f32_mode() < 0) return fail(1, "row attention: the all-VALU cross-check kernels have no <pad> handling");
   const int n_chunk = (C + 63) / 64;
   const int ldS = msa_row_scores_ld(C);         // `scores` holds B*H*C rows of ldS floats
   if (attn_f32_mode() < 0) {
@@ -563,13 +585,13 @@ int launch_msa_row_attention_f32(hipStream_t s, const float* qkv, float* scores,
   } else {
     if (C <= 64) {
       hipLaunchKernelGGL(msa_row_scores_split_kernel<4>, dim3((unsigned)(B * H * n_chunk)), dim3(256), 0, s, qkv, scores, R, C, H,
-                         ld_qkv, k_off, scale, n_chunk, 1, ldS);
+                         ld_qkv, k_off, scale, n_chunk, 1, ldS, tok, pad_idx);
       hipLaunchKernelGGL(msa_row_apply_split_kernel<4>, dim3((unsigned)(B * H * R * n_chunk)), dim3(256), 0, s, qkv, scores, ctx,
                          split_d, R, C, H, ld_qkv, ld_ctx, v_off, n_chunk, ldS);
     } else {
       const int n_ktile = (C + 159) / 160;
       hipLaunchKernelGGL(msa_row_scores_split_kernel<10>, dim3((unsigned)(B * H * n_chunk * n_ktile)), dim3(256), 0, s, qkv, scores,
-                         R, C, H, ld_qkv, k_off, scale, n_chunk, n_ktile, ldS);
+                         R, C, H, ld_qkv, k_off, scale, n_chunk, n_ktile, ldS, tok, pad_idx);
       hipLaunchKernelGGL(msa_row_apply_split_kernel<10>, dim3((unsigned)(B * H * R * n_chunk)), dim3(256), 0, s, qkv, scores, ctx,
                          split_d, R, C, H, ld_qkv, ld_ctx, v_off, n_chunk, ldS);
     }
@@ -584,6 +606,7 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
   if (n_seq == 0) return 0;
   if (T <= 0) return fail(1, "attention: empty sequence");
   if (bias_kv && attn_f32_mode() < 0) return fail(1, "attention: the all-VALU cross-check kernel has no bias_k / bias_v key (ESM-1)");
+  if (key_tok && sl.row_step != 1 && attn_f32_mode() < 0) return fail(1, "attention: the all-VALU cross-check kernel masks <pad> keys of contiguous chains only");
   const int mode = attn_f32_mode();
   // 16-query blocks per wave of the split kernel (its workgroup = 64 * nqb queries, all of them against each staged K / V tile):
   // the smallest of 1, 2, 3, 5 that covers the sequence with one workgroup, else 5 (PGIBBS_ATTN_F32_NQB overrides: A/B runs)

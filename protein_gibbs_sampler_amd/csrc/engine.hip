@@ -563,6 +563,14 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
   const float eps = cfg.layer_norm_eps;
   const int Mi = (int)Mp;
   const float row_scale = 0.125f / sqrtf((float)R);      // dh^-0.5 / sqrt(R): depends on R, applied to the scores
+  // A batch that holds <pad> (a ragged list of MSAs padded to one tensor by the unmasked log_likelihood_batch, esm_msa_sampler.py:341,
+  // 416-431; set by the host-token entry points): fair-esm's padding semantics -- tied row attention with q zeroed at <pad>
+  // positions and row 0's <pad> columns filled with -10000 (the scores-through-scratch kernels), column attention with <pad> key
+  // rows filled with -10000.  R, and with it the 1/sqrt(R) of the row attention, is the padded row count, as in the reference.
+  const int32_t* pad_tok = esm_pad_in_batch ? d_tok : nullptr;
+  if (pad_tok && precision == PG_PREC_F16)
+    return fail(PG_ERR_UNSUPPORTED, "fp16 precision mode: batches with <pad> (ragged MSA lists) take the scores-through-scratch row "
+                                    "attention, which exists for bf16 operands only -- use precision bf16 or fp32");
   if (strict()) {
     if ((rc = h.ensure((size_t)Mp * 3 * d * 2, stream)) || (rc = ctx.ensure((size_t)Mp * 3 * d * 2, stream))) return rc;   // [lo | hi | hi] rows
     if ((rc = qkv.ensure((size_t)Mp * 3 * d * 4, stream))) return rc;
@@ -583,11 +591,11 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       const MsaLayer& L = msa_layers[l];
       if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_row.g, L.ln_row.b, H3, M, d, eps2, true); }))) return rc;
       if ((rc = dense3(H3, L.row_qkv, QKVf, Mi2, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_f32(stream, QKVf, scores.as<float>(), C3, d, B, R, C, H, 3 * d, 3 * d, d, 2 * d, row_scale); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_f32(stream, QKVf, scores.as<float>(), C3, d, B, R, C, H, 3 * d, 3 * d, d, 2 * d, row_scale, pad_tok, cfg.pad_idx); }))) return rc;
       if ((rc = dense3(C3, L.row_out, Xs, Mi2, true))) return rc;
       if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_col.g, L.ln_col.b, H3, M, d, eps2, true); }))) return rc;
       if ((rc = dense3(H3, L.col_qkv, QKVf, Mi2, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, C3, d, (int64_t)B * C, R, H, 3 * d, 3 * d, d, 2 * d, colS); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, C3, d, (int64_t)B * C, R, H, 3 * d, 3 * d, d, 2 * d, colS, pad_tok, cfg.pad_idx); }))) return rc;
       if ((rc = dense3(C3, L.col_out, Xs, Mi2, true))) return rc;
       if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_ffn.g, L.ln_ffn.b, H3, M, d, eps2, true); }))) return rc;
       if ((rc = dense3_gelu(H3, L.fc1, Mi2))) return rc;
@@ -608,7 +616,7 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     const MsaLayer& L = msa_layers[l];
     // tied row attention
     if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.row_qkv.w, L.row_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
-    if (C <= 576) {
+    if (C <= 576 && !pad_tok) {
       float* part = nullptr;
       // few workgroups: give the kernel scratch for its split-R mode (decided on the job's batch: the split changes the
       // order of the sum over alignment rows, and a shard must compute what the whole batch would)
@@ -630,14 +638,14 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
         int r2 = launch_bf16_to_f32(stream, QKV, scratch.as<float>(), (int64_t)M * 3 * d);
         if (r2) return r2;
         return launch_msa_row_attention_f32(stream, scratch.as<float>(), scores.as<float>(), CTX, 0, B, R, C, H,
-                                            3 * d, d, d, 2 * d, row_scale);
+                                            3 * d, d, d, 2 * d, row_scale, pad_tok, cfg.pad_idx);
       });
       if (rc) return rc;
     }
     if ((rc = resid_gemm_ln(CTX, L.row_out, X, Mi, M, d, L.ln_col, Hh, nullptr, 0, PC_GEMM_OUT))) return rc;                 // x += row_out(ctx); h = LN_col(x)
     // column attention (q pre-scaled by dh^-0.5 in the weights)
     if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
-    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_seq_bf16, stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col); }))) return rc;
+    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_seq_bf16, stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col, pad_tok, cfg.pad_idx, nullptr); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: nothing but the selected rows is read again -> finish column out-projection and FFN on n_sel rows
       const int64_t Np = round_up64(n_sel, kRowPad);

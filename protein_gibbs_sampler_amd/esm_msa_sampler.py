@@ -291,13 +291,52 @@ class ESM_MSA_sampler():
                              mask_distance=float("inf"), batch_size=1):
         """Same contract as pgen.esm_msa_sampler.ESM_MSA_sampler.log_likelihood_batch: yields (float mean, list[float])
         for the row `target_index` of every MSA; gap positions of the target row are skipped unless count_gaps.
-        Every MSA is scored on its own tokens (no padding reaches the model)."""
+        with_masking: every MSA is scored on its own strided-mask copies (no padding reaches the model, as in the reference,
+        :365-405).  Unmasked: the reference converts the WHOLE list into one tensor padded to the deepest / widest MSA and scores
+        `batch_size` of them per forward (:341, :416-431) -- so a shallower MSA of a ragged list is scored with <pad> rows and
+        columns around it under fair-esm's padding semantics (and its tied row attention's 1/sqrt(R) from the padded depth); the
+        same here, through the engine's <pad> handling."""
         self._require_gpu("log_likelihood_batch")
         gap_tokens = {self.model.alphabet.get_idx(x) for x in ESM_MSA_GAP_CHARACTERS}
         if batch_size is None:
             batch_size = len(msa_list)
         range_start = 1 if self.model.alphabet.prepend_bos else 0
         mask_idx = self.model.alphabet.mask_idx
+        if not with_masking:
+            if not msa_list:
+                return
+            reformatted = [[(str(i), self.clean_seed_seq(seq)) for i, seq in enumerate(msa)] for msa in msa_list]
+            _, _, tokens = self.model.batch_converter(reformatted)          # [n, R_max, C_max], <pad> around the smaller MSAs
+            n, R, C = tokens.shape
+            for batch_start in range(0, n, max(1, batch_size)):
+                chunk = tokens[batch_start:batch_start + max(1, batch_size)]
+                nb = chunk.shape[0]
+                pos_of, orig = [], []
+                for i in range(nb):
+                    msa = msa_list[batch_start + i]
+                    tr = target_index if target_index >= 0 else R + target_index      # tokens[:, target_index] of the PADDED tensor (:370)
+                    o = chunk[i, tr].numpy()
+                    end = len(msa[target_index]) + range_start
+                    pos_of.append([p_ for p_ in range(range_start, end) if count_gaps or int(o[p_]) not in gap_tokens])
+                    orig.append(o)
+                P = max((len(p_) for p_ in pos_of), default=0)
+                idx = np.full((nb, max(P, 1)), -1, dtype=np.int32)
+                tgt = np.zeros((nb, max(P, 1)), dtype=np.int32)
+                for i, pos in enumerate(pos_of):
+                    idx[i, :len(pos)] = pos
+                    tgt[i, :len(pos)] = orig[i][pos]
+                tr = target_index if target_index >= 0 else R + target_index
+                lp = _gibbs.score_positions(self.model.model, chunk, np.arange(nb) * R + tr, idx, tgt, self.device)
+                for i in range(nb):
+                    msa = msa_list[batch_start + i]
+                    denom = len(msa[target_index]) - (0 if count_gaps else sum(msa[target_index].count(g) for g in ESM_MSA_GAP_CHARACTERS))
+                    likelihood_sum = np.float32(0.0)
+                    likelihood_list = []
+                    for p_ in range(len(pos_of[i])):
+                        likelihood_sum = np.float32(likelihood_sum + lp[i, p_])
+                        likelihood_list.append(float(lp[i, p_]))
+                    yield (float(likelihood_sum / np.float32(denom)), likelihood_list)
+            return
         for msa in msa_list:
             reformatted = [(str(i), self.clean_seed_seq(seq)) for i, seq in enumerate(msa)]
             _, _, one = self.model.batch_converter(reformatted)            # [1, R, C]
@@ -307,16 +346,11 @@ class ESM_MSA_sampler():
             denom = seq_len - (0 if count_gaps else sum(msa[target_index].count(g) for g in ESM_MSA_GAP_CHARACTERS))
             end = seq_len + range_start
             orig = one[0, tr].numpy()
-            if with_masking:
-                n = int(min(mask_distance, seq_len))
-                copies = one.repeat(n, 1, 1)
-                pos_all = [list(range(range_start + i, end, n)) for i in range(n)]
-                for i, pos in enumerate(pos_all):
-                    copies[i, tr, pos] = mask_idx
-            else:
-                n = 1
-                copies = one
-                pos_all = [list(range(range_start, end))]
+            n = int(min(mask_distance, seq_len))
+            copies = one.repeat(n, 1, 1)
+            pos_all = [list(range(range_start + i, end, n)) for i in range(n)]
+            for i, pos in enumerate(pos_all):
+                copies[i, tr, pos] = mask_idx
             pos_of = [[p for p in pos if count_gaps or int(orig[p]) not in gap_tokens] for pos in pos_all]
             P = max((len(p) for p in pos_of), default=0)
             idx = np.full((n, max(P, 1)), -1, dtype=np.int32)

@@ -22,15 +22,21 @@ def _ln(x, w, p):
     return F.layer_norm(x, (x.shape[-1],), torch.from_numpy(w[p + ".weight"]), torch.from_numpy(w[p + ".bias"]), 1e-5)
 
 
-def _row_attention(w, p, x, H, max_tokens):
+def _row_attention(w, p, x, H, max_tokens, padding_mask=None):
     R, C, B, D = x.shape
     dh = D // H
     scaling = (dh ** -0.5) / math.sqrt(R)                       # align_scaling: from the full number of rows
 
-    def weights(xc):
+    def weights(xc, pm):                                        # pm: padding mask [B, rows of this chunk, C] or None
         q = _lin(xc, w, p + "q_proj").view(xc.shape[0], C, B, H, dh) * scaling
         k = _lin(xc, w, p + "k_proj").view(xc.shape[0], C, B, H, dh)
-        return torch.einsum("rinhd,rjnhd->hnij", q, k)
+        if pm is not None:
+            # "Zero out any padded aligned positions - this is important since we take a sum across the alignment axis."
+            q = q * (1 - pm.permute(1, 2, 0).unsqueeze(3).unsqueeze(4).to(q))
+        a = torch.einsum("rinhd,rjnhd->hnij", q, k)
+        if pm is not None:
+            a = a.masked_fill(pm[:, 0].unsqueeze(0).unsqueeze(2), -10000)      # row 0 OF THE CHUNK, as fair-esm's batched path does
+        return a
 
     def update(xc, probs):
         v = _lin(xc, w, p + "v_proj").view(xc.shape[0], C, B, H, dh)
@@ -38,34 +44,38 @@ def _row_attention(w, p, x, H, max_tokens):
         return _lin(ctx, w, p + "out_proj")
 
     if R * C <= max_tokens:
-        return update(x, weights(x).softmax(-1))
+        return update(x, weights(x, padding_mask).softmax(-1))
     max_rows = max(1, max_tokens // C)
     attns = 0
     for s in range(0, R, max_rows):
-        attns = attns + weights(x[s:s + max_rows])
+        attns = attns + weights(x[s:s + max_rows], None if padding_mask is None else padding_mask[:, s:s + max_rows])
     probs = attns.softmax(-1)
     return torch.cat([update(x[s:s + max_rows], probs) for s in range(0, R, max_rows)], 0)
 
 
-def _column_attention(w, p, x, H, max_tokens):
+def _column_attention(w, p, x, H, max_tokens, padding_mask=None):
     R, C, B, D = x.shape
     dh = D // H
 
-    def block(xc):
+    def block(xc, pm=None):
         if R == 1:
             return _lin(_lin(xc, w, p + "v_proj"), w, p + "out_proj")
         c = xc.shape[1]
         q = _lin(xc, w, p + "q_proj").view(R, c, B, H, dh) * dh ** -0.5
         k = _lin(xc, w, p + "k_proj").view(R, c, B, H, dh)
         v = _lin(xc, w, p + "v_proj").view(R, c, B, H, dh)
-        probs = torch.einsum("icnhd,jcnhd->hcnij", q, k).softmax(-1)
+        a = torch.einsum("icnhd,jcnhd->hcnij", q, k)
+        if pm is not None:
+            a = a.masked_fill(pm.permute(2, 0, 1).unsqueeze(0).unsqueeze(3), -10000)
+        probs = a.softmax(-1)
         ctx = torch.einsum("hcnij,jcnhd->icnhd", probs, v).contiguous().view(R, c, B, D)
         return _lin(ctx, w, p + "out_proj")
 
     if R * C <= max_tokens:
-        return block(x)
+        return block(x, padding_mask)
     max_cols = max(1, max_tokens // R)
-    return torch.cat([block(x[:, s:s + max_cols]) for s in range(0, C, max_cols)], 1)
+    return torch.cat([block(x[:, s:s + max_cols], None if padding_mask is None else padding_mask[:, :, s:s + max_cols])
+                      for s in range(0, C, max_cols)], 1)
 
 
 def msa_forward_alt(w, n_layers, n_heads, tokens, pad_idx=1, max_tokens_per_msa=2 ** 14):
@@ -82,12 +92,13 @@ def msa_forward_alt(w, n_layers, n_heads, tokens, pad_idx=1, max_tokens_per_msa=
     x = _ln(x, w, "emb_layer_norm_before")
     x = x * (1 - pad.unsqueeze(-1).type_as(x))
     x = x.permute(1, 2, 0, 3)                                   # B x R x C x D -> R x C x B x D
+    pm = pad if bool(pad.any()) else None                       # `if not padding_mask.any(): padding_mask = None`
     for i in range(n_layers):
         p = "layers.%d." % i
         x = x + _row_attention(w, p + "row_self_attention.layer.", _ln(x, w, p + "row_self_attention.layer_norm"), n_heads,
-                               max_tokens_per_msa)
+                               max_tokens_per_msa, pm)
         x = x + _column_attention(w, p + "column_self_attention.layer.", _ln(x, w, p + "column_self_attention.layer_norm"),
-                                  n_heads, max_tokens_per_msa)
+                                  n_heads, max_tokens_per_msa, pm)
         h = _ln(x, w, p + "feed_forward_layer.layer_norm")
         h = F.gelu(_lin(h, w, p + "feed_forward_layer.layer.fc1"))
         x = x + _lin(h, w, p + "feed_forward_layer.layer.fc2")

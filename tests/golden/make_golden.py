@@ -87,7 +87,13 @@ def _standin(arch, context=False):
             t = convert_rows(inputs)
             return [l for l, _ in inputs], [s for _, s in inputs], t
         raw = [inputs] if isinstance(inputs[0][0], str) else inputs
-        return None, None, torch.stack([convert_rows(m) for m in raw])
+        # as the reference's patched MSABatchConverter (/root/reference/src/pgen/models.py:23-55): one tensor of the deepest /
+        # widest MSA, <pad> elsewhere
+        conv = [convert_rows(m) for m in raw]
+        out = torch.full((len(conv), max(c.shape[0] for c in conv), max(c.shape[1] for c in conv)), alphabet.padding_idx, dtype=torch.int64)
+        for i, c in enumerate(conv):
+            out[i, :c.shape[0], :c.shape[1]] = c
+        return None, None, out
 
     class Net(torch.nn.Module):
         """Deterministic logits: a fixed pseudo-random function of (token at position, position,
@@ -404,13 +410,24 @@ def gen_loglik():
     for kw in (dict(target_index=0), dict(target_index=1, mask_distance=3), dict(target_index=2, count_gaps=True, mask_distance=4),
                dict(target_index=0, with_masking=False), dict(target_index=1, with_masking=False, count_gaps=True),
                dict(target_index=-1, mask_distance=2, batch_size=2)):
-        means, lists = [], []
-        for msa in msas:       # one MSA per call: the reference pads ragged batches, this package scores MSAs separately
-            s = refm.ESM_MSA_sampler(_standin("msa1b"), device="cpu")
-            for m, l in s.log_likelihood_batch([list(msa)], **kw):
+        # the whole ragged list in ONE call: the unmasked path pads it to one [n, R_max, C_max] tensor (esm_msa_sampler.py:341,
+        # 416-431), so the shallower / narrower MSA is scored with <pad> around it -- reproduced by this package since round 4
+        s = refm.ESM_MSA_sampler(_standin("msa1b"), device="cpu")
+        means, lists, per_msa = [], [], False
+        try:
+            for m, l in s.log_likelihood_batch([list(msa) for msa in msas], **kw):
                 means.append(m)
                 lists.append(l)
-        out["msa"].append(dict(msas=msas, kw=kw, means=means, lists=lists))
+        except AssertionError:
+            # target_index = -1 on a list of different depths: the reference reads tokens[:, -1] of the PADDED tensor (:370), counts
+            # the shallower MSA's <pad> row and trips its own `len(counted_idx) == msa_denominator` check -- recorded per MSA instead
+            means, lists, per_msa = [], [], True
+            for msa in msas:
+                s = refm.ESM_MSA_sampler(_standin("msa1b"), device="cpu")
+                for m, l in s.log_likelihood_batch([list(msa)], **kw):
+                    means.append(m)
+                    lists.append(l)
+        out["msa"].append(dict(msas=msas, kw=kw, means=means, lists=lists, per_msa=per_msa))
     with open(os.path.join(HERE, "loglik.json"), "w") as f:
         json.dump(out, f)
     print("loglik.json written:", len(out["esm"]), len(out["msa"]))

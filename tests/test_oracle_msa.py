@@ -103,3 +103,37 @@ def test_oracle_equals_fair_esm_layout_restatement_and_chunked_paths():
         for max_tokens in (C * 2, C + 3, 7):                    # 2 rows per chunk / 1 row + ragged columns / tiny
             chunked = msa_forward_alt(sd, 2, 2, tok, max_tokens_per_msa=max_tokens)
             assert np.abs(chunked - alt).max() < 2e-5 * max(1.0, np.abs(alt).max())
+
+
+def test_padded_ragged_msa_batch_oracle_vs_fair_esm_layout_restatement():
+    """Ragged MSA lists (the reference's unmasked log_likelihood_batch pads them to one [n, R_max, C_max] tensor,
+    /root/reference/src/pgen/esm_msa_sampler.py:341,416-431): <pad> rows and <pad> columns under fair-esm's padding semantics -- q
+    zeroed at padded positions of the tied row attention, key columns that are <pad> in row 0 and key rows that are <pad> at a
+    column filled with -10000, the 1/sqrt(R) from the padded row count.  The two restatements must agree, the padded MSA's real
+    positions must differ from the same MSA scored alone (the artefact the reference has: R_max enters the scaling), and a batch
+    without <pad> must not change."""
+    from _msa_alt import msa_forward_alt
+    ck = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=80, max_rows=16)
+    ocfg = MsaConfig(**ck)
+    sd = synthetic_msa_weights(ocfg, seed=23, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    rng = np.random.default_rng(6)
+    shapes = [(6, 21), (4, 17), (6, 12)]                        # (rows, columns incl. <cls>) of three MSAs
+    R, C = 6, 21
+    tok = np.full((3, R, C), 1, dtype=np.int64)
+    for b, (r, c) in enumerate(shapes):
+        tok[b, :r, :c] = rng.integers(4, 24, (r, c))
+        tok[b, :r, 0] = 0
+    want = msa_forward(sd, ocfg, tok)
+    alt = msa_forward_alt(sd, 2, 2, tok)
+    assert np.isfinite(want).all()
+    for b, (r, c) in enumerate(shapes):
+        assert np.abs(alt[b, :r, :c] - want[b, :r, :c]).max() < 5e-5 * max(1.0, np.abs(want).max())
+    # MSA 0 has no padding of its own but shares the batch: same as alone (fair-esm masks per MSA; R_max == its own R)
+    alone0 = msa_forward(sd, ocfg, tok[:1])
+    assert np.abs(alone0[0] - want[0]).max() < 2e-5
+    # MSA 1 padded from 4 to 6 rows: the row-attention scaling uses 6 -> differs from scoring it alone
+    alone1 = msa_forward(sd, ocfg, tok[1:2, :4, :17])
+    assert np.abs(alone1[0] - want[1, :4, :17]).max() > 1e-3
+    # MSA 2 padded in columns only (same rows): equals scoring it alone up to rounding -- pad columns are masked keys, masked column-attention rows
+    alone2 = msa_forward(sd, ocfg, tok[2:3, :, :12])
+    assert np.abs(alone2[0] - want[2, :, :12]).max() < 5e-5 * max(1.0, np.abs(want).max())
