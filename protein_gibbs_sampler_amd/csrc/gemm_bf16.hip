@@ -965,6 +965,9 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
     const bool pp_sized = M % 256 == 0 && N % 256 == 0 && (long)(M / 256) * (N / 256) >= 128;   // the 256^2 kernel fills the chip
     const bool small = M <= 48 || ((M <= 256 || M % 64 == 0) && t64 * splits <= 1280 && !pp_sized);
     const long stride = (long)Mr * N;
+    // (round 4: ONE launch of N / 16 workgroups with 16 waves splitting K instead of the K-splits + reduction was measured slower,
+    // config 1 1.73 -> 1.92 ms per iteration: every workgroup re-reads the whole [M][K] operand, 327 KB at K = 5120, and a CU's
+    // L2 -> L1 path carries ~130 GB/s -- the K-splits spread those reads over four times as many CUs)
     if (splits > 1 && small && (size_t)splits * stride * 4 <= ws_bytes && (K / splits) % 64 == 0) {
       int rc;
       const int Ks = K / splits;
