@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4 evidence set from one HEAD: full GPU test suite, the default bench line, a 50-iteration job, rocprofv3 kernel stats
+# (configs 2, 1 and 4), PMC fabric traffic, the shard regime.  Everything the profiles/r04_* files are copied from.
+cd "${GRAFT_REPO_ROOT:-.}"
+O=gpurun_out/r04ev; mkdir -p $O
+( time python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
+python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json
+python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strict --no-fp16 --no-msa > $O/bench_50iters.json 2>> $O/bench_default.err
+bash tools/r03_prof.sh r04ev > $O/prof_cfg2.txt 2>&1; tail -16 $O/prof_cfg2.txt | cut -c1-170
+bash tools/r03_prof_msa.sh r04ev 4 > $O/prof_msa4.txt 2>&1; tail -16 $O/prof_msa4.txt | cut -c1-170
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profc1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc1 -o p -- python $GRAFT_REPO_ROOT/tools/cfg1_probe.py > /tmp/profc1.log 2>&1; cp $(find /tmp/profc1 -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/cfg1_kernel_stats.csv )
+bash tools/pmc_traffic.sh r04 > $O/traffic.txt 2>&1; tail -14 $O/traffic.txt | cut -c1-170
+python tools/shard_regime.py --engine > $O/shard_regime.txt 2>&1; tail -8 $O/shard_regime.txt
