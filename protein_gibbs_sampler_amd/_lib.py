@@ -12,7 +12,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpgibbs.so")
+LIB_PATH = os.environ.get("PGIBBS_LIB_PATH") or os.path.join(_HERE, "lib", "libpgibbs.so")     # override: A/B runs of two builds
 
 PG_OK = 0
 PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_NO_DEVICE, PG_ERR_WEIGHTS, PG_ERR_UNSUPPORTED = 1, 2, 3, 4, 5

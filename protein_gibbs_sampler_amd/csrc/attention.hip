@@ -41,7 +41,9 @@ __device__ unsigned long long* pg_att_prof;      // [workgroup][wave][8 slots][8
 #define PG_T(slot, i)
 #endif
 
-template <int MAXKB, bool PADMASK>
+// BIASKV: ESM-1's extra bias_k / bias_v key (a template parameter: the extra staging branch and the runtime key count cost the
+// config-2 kernel 8 % when they were runtime conditions)
+template <int MAXKB, bool PADMASK, bool BIASKV = false>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                        SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx,
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
   const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
   // ESM-1 (add_bias_kv): key T is the learned bias_k / bias_v of this head -- one more key, attended by every query, never masked
-  const int Tk = T + (bias_kv ? 1 : 0);
+  const int Tk = T + (BIASKV ? 1 : 0);
   // All MAXKB key blocks are computed unconditionally: K rows / V^T columns past T are zero-filled and
   // their scores are masked, so no wave-uniform branches (and no dynamic register indexing) are needed.
   constexpr int nkc = MAXKB / 2;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       if (i < tpad * 8 && row < T) {
         kreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + k_off + c * 8);
         vreg[it] = *(const uint4*)(base + (size_t)row * ld_qkv + v_off + c * 8);
-      } else if (bias_kv && row == T) {
+      } else if (BIASKV && row == T) {
         kreg[it] = *(const uint4*)(bias_kv + h * 64 + c * 8);
         vreg[it] = *(const uint4*)(bias_kv + (H + h) * 64 + c * 8);
       }
@@ -443,7 +445,9 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   dim3 grid((unsigned)(n_seq * H)), block(256);
 #define PG_ATT(KB)                                                                                             \
   else if (Tk <= KB * 16) {                                                                                    \
-    if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    if (bias_kv && key_tok) hipLaunchKernelGGL((attention_kernel<KB, true, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else if (bias_kv) hipLaunchKernelGGL((attention_kernel<KB, false, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
     else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
   }
   const int Tk = T + (bias_kv ? 1 : 0);          // keys: the T tokens + ESM-1's bias_k / bias_v

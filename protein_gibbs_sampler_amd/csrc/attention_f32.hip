@@ -63,6 +63,7 @@ struct SplitAttn {
   // rows 0 .. tpad-1 of 64 fp32 at src + row*ld (rows >= n_valid read as zero) -> (hi, lo) bf16 tiles; a tile row is
   // 128 B with its 16-B chunks XOR-swizzled: row*128 + ((c ^ (row & 7)) << 4).  All global loads in flight first.
   // extra (optional): 64 fp32 that stand in for row n_valid (ESM-1: the head's bias_k / bias_v behind the last token)
+  template <bool EXTRA = false>
   static __device__ __forceinline__ void stage(const float* __restrict__ src, size_t ld, int n_valid, char* Xh, char* Xl, int tid,
                                                const float* __restrict__ extra = nullptr) {
     constexpr int NIT = (tpad * 8 + 255) / 256;      // one item = 8 d of one key
@@ -76,7 +77,7 @@ struct SplitAttn {
         const float4* p = (const float4*)(src + (size_t)row * ld + c * 8);
         r0[it] = p[0];
         r1[it] = p[1];
-      } else if (extra && row == n_valid && i < tpad * 8) {
+      } else if (EXTRA && row == n_valid && i < tpad * 8) {
         const float4* p = (const float4*)(extra + c * 8);
         r0[it] = p[0];
         r1[it] = p[1];
@@ -213,7 +214,7 @@ struct SplitAttn {
 // (sequence, head) instead of five that each re-staged and re-split the same 132 KB of fp32 K and V (round 3: 28 ms of the strict
 // config-2 iteration were this kernel, 4x the bf16 mode's, most of it the 5x redundant fp32 tile traffic).  The per-query
 // arithmetic (tile order, products, rounding points) is unchanged: identical bits.
-template <int MAXKB, int NQB>
+template <int MAXKB, int NQB, bool BIASKV = false, bool PADMASK = false>
 __global__ __launch_bounds__(256, 2) void attention_split_kernel(
     const float* __restrict__ qkv, bf16_t* __restrict__ ctx, int split_d, int T, int H, int ld_qkv_, int ld_ctx_, int k_off,
     int v_off, SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok, int pad_idx, const float* __restrict__ bias_kv) {
@@ -240,13 +241,13 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
   }
 
   // ESM-1 (add_bias_kv): key T = this head's bias_k / bias_v -- one more key, never masked (attention.hip)
-  const int Tk = T + (bias_kv ? 1 : 0);
-  const float* bk = bias_kv ? bias_kv + h * 64 : nullptr;
-  const float* bv = bias_kv ? bias_kv + (H + h) * 64 : nullptr;
+  const int Tk = T + (BIASKV ? 1 : 0);
+  const float* bk = BIASKV ? bias_kv + h * 64 : nullptr;
+  const float* bv = BIASKV ? bias_kv + (H + h) * 64 : nullptr;
   for (int k0 = 0; k0 < Tk; k0 += tpad) {
     __syncthreads();
-    A::stage(base + (size_t)k0 * ld_qkv + k_off, ld_qkv, T - k0, Kh, Kl, tid, bk);
-    A::stage(base + (size_t)k0 * ld_qkv + v_off, ld_qkv, T - k0, Vh, Vl, tid, bv);
+    A::template stage<BIASKV>(base + (size_t)k0 * ld_qkv + k_off, ld_qkv, T - k0, Kh, Kl, tid, bk);
+    A::template stage<BIASKV>(base + (size_t)k0 * ld_qkv + v_off, ld_qkv, T - k0, Vh, Vl, tid, bv);
     __syncthreads();
     const int tl = Tk - k0 - fq * 4;             // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
 #pragma unroll
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
-      if (key_tok) {      // <pad> keys of a ragged batch: token of key t at key_tok[row0 + t * row_step]; -inf for chains, fair-esm's
+      if (PADMASK) {      // <pad> keys of a ragged batch: token of key t at key_tok[row0 + t * row_step]; -inf for chains, fair-esm's
                           // finite -10000 for the MSA Transformer's column attention (attention.hip)
         const int32_t* kt = key_tok + row0 + (size_t)k0 * sl.row_step;
         const float fill = sl.row_step == 1 ? -3.0e38f : -10000.0f;
@@ -625,8 +626,16 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
     // key tile: 64 keys for short sequences, else 160 (80 KB of LDS: two workgroups per CU; at T = 258 a single 288-key
     // tile with one workgroup per CU was 1.6x slower)
 #define PG_ATT_SPLIT(KB, NQ)                                                                                                  \
-  hipLaunchKernelGGL((attention_split_kernel<KB, NQ>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
-                     n_qchunk, key_tok, pad_idx, bias_kv)
+  do {                                                                                                                        \
+    if (bias_kv && key_tok) hipLaunchKernelGGL((attention_split_kernel<KB, NQ, true, true>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
+                                               n_qchunk, key_tok, pad_idx, bias_kv);                                           \
+    else if (bias_kv) hipLaunchKernelGGL((attention_split_kernel<KB, NQ, true, false>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
+                                         n_qchunk, key_tok, pad_idx, bias_kv);                                                 \
+    else if (key_tok) hipLaunchKernelGGL((attention_split_kernel<KB, NQ, false, true>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
+                                         n_qchunk, key_tok, pad_idx, bias_kv);                                                 \
+    else hipLaunchKernelGGL((attention_split_kernel<KB, NQ, false, false>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
+                            n_qchunk, key_tok, pad_idx, bias_kv);                                                              \
+  } while (0)
     if (T < 64 || (T == 64 && !bias_kv)) PG_ATT_SPLIT(4, 1);
     else if (nqb == 1) PG_ATT_SPLIT(10, 1);
     else if (nqb == 2) PG_ATT_SPLIT(10, 2);

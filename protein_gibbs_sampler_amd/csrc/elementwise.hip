@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
         v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
       }
     }
-  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  if (gamma) ln_inplace(v, nch4, lane, d, eps, gamma, beta);      // gamma == nullptr: no emb_layer_norm_before (ESM-1)
   float4* o = (float4*)(x + (size_t)row * d);
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void lm_tail_kernel(const float* __restrict__ 
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
-  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  if (gamma) ln_inplace(v, nch4, lane, d, eps, gamma, beta);      // gamma == nullptr: ESM-1's head has no LayerNorm
   float mine = 0.f;  // lane t keeps logit t (V <= 64)
   // four decoder rows per trip: their loads are all in flight before the first reduction (one row per trip was a chain
   // of V dependent L2 round trips: 81 us for a handful of rows)
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(1024) void lm_tail_small_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
-  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  if (gamma) ln_inplace(v, nch4, lane, d, eps, gamma, beta);
   float s[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {

@@ -18,7 +18,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 // normalise the row held in v[] (chunk c = lane + 64*i) in place: (x-mean)/sqrt(var+eps)*g + b
 __device__ __forceinline__ void ln_inplace(float4 (&v)[kMaxCh], int nch4, int lane, int d, float eps,
                                            const float* __restrict__ gamma, const float* __restrict__ beta) {
-  if (!gamma) return;                      // no LayerNorm here (ESM-1: no emb_layer_norm_before / after): the row passes through
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
