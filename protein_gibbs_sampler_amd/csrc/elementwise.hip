@@ -104,6 +104,29 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   store_row_bf16(h + (size_t)row * d * (split3 ? 3 : 1), v, nch4, lane, split3);
 }
 
+// The same with the output rows in COLUMN-MAJOR token order: token row (b*R + r)*C + c -> operand row (b*C + c)*R + r, so that a
+// column's R tokens are contiguous rows for the fused column QKV + attention kernel (gemm_colattn.hip).  A separate kernel: the hot
+// LayerNorm above stays as it is.
+__global__ __launch_bounds__(256) void layernorm_bf16_colmajor_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, bf16_t* __restrict__ h,
+                                                                     int64_t M, int d, float eps, int R, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch4 = d >> 2;
+  const float4* x4 = (const float4*)(x + (size_t)row * d);
+  float4 v[kMaxCh];
+#pragma unroll
+  for (int i = 0; i < kMaxCh; ++i)
+    if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
+  ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+  const int64_t br = row / C;
+  const int c = (int)(row - br * C);
+  const int64_t b = br / R;
+  const int r = (int)(br - b * R);
+  store_row_bf16(h + (size_t)((b * C + c) * R + r) * d, v, nch4, lane);
+}
+
 // fp32 -> fp32 LayerNorm (debug entry / strict paths)
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ y,
@@ -321,9 +344,15 @@ int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, co
 }
 
 int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
-                          int d, float eps, bool split3) {
+                          int d, float eps, bool split3, int colmajor_R, int colmajor_C) {
   if (d % 4 || d > kMaxCh * 256) return fail(1, "layernorm: d must be a multiple of 4 and <= 2048");
   if (M == 0) return 0;
+  if (colmajor_R > 0) {
+    if (split3 || M % ((int64_t)colmajor_R * colmajor_C)) return fail(1, "layernorm: column-major output needs whole MSAs and plain bf16 rows");
+    hipLaunchKernelGGL(layernorm_bf16_colmajor_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, M, d, eps, colmajor_R, colmajor_C);
+    PG_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, split3 ? 1 : 0, M, d, eps);
   PG_HIP(hipGetLastError());
   return 0;

@@ -47,6 +47,7 @@ struct EsmLayer {
 struct MsaLayer {
   LnW ln_row, ln_col, ln_ffn;
   DenseW row_qkv, row_out, col_qkv, col_out, fc1, fc2;
+  DenseW col_qkv_hm;      // col_qkv with its rows grouped per head ([q_h | k_h | v_h]): operand of the fused column kernel (gemm_colattn.hip)
 };
 
 struct Engine {
@@ -70,7 +71,7 @@ struct Engine {
   DevBuf x_sel, ctx_sel, h_sel, ffn_sel;   // last-layer pruning (compact rows)
   // x (+)= a W^T + b, then h = LayerNorm(x; ln): residual GEMM + LayerNorm kernel
   int resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
-                    float* ws = nullptr, size_t ws_bytes = 0, int prof_class = PC_GEMM);
+                    float* ws = nullptr, size_t ws_bytes = 0, int prof_class = PC_GEMM, int colmajor_R = 0, int colmajor_C = 0);
   DevBuf tmp_idx, tmp_out;                 // batched generate_single on small MSAs: one template's step table / outputs
   DevBuf splitk;                           // fp32 partial maps of split-K fc2 GEMMs (small batches)
   bool esm_pad_in_batch = false;           // set by the host-token entry points: some token is <pad> -> key-padding mask

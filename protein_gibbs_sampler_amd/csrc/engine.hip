@@ -176,6 +176,22 @@ struct Uploader {
     L.bias_kv16 = (bf16_t*)d16;
     return true;
   }
+  // a [q | k | v] projection with its rows regrouped per head (the fused column QKV + attention kernel's weight operand)
+  bool headmajor(DenseW& out, const DenseW& in, int H) {
+    void *dw = nullptr, *db = nullptr;
+    if (hipMalloc(&dw, (size_t)in.N * in.K * 2) != hipSuccess || hipMalloc(&db, (size_t)in.N * 4) != hipSuccess) { err = "hipMalloc failed (head-major projection)"; return false; }
+    e->owned.push_back(dw);
+    e->owned.push_back(db);
+    const bool ok = (e->precision == PG_PREC_F16 ? opf16::launch_headmajor_qkv(e->stream, in.w, in.b, (bf16_t*)dw, (float*)db, H, in.K)
+                                                 : opbf16::launch_headmajor_qkv(e->stream, in.w, in.b, (bf16_t*)dw, (float*)db, H, in.K)) == 0 &&
+                    hipStreamSynchronize(e->stream) == hipSuccess;
+    if (!ok) { err = "head-major projection copy failed"; return false; }
+    out.w = (bf16_t*)dw;
+    out.b = (float*)db;
+    out.N = in.N;
+    out.K = in.K;
+    return true;
+  }
   bool ln(LnW& out, const std::string& prefix, int d) {
     out.g = f32(prefix + ".weight", d);
     out.b = out.g ? f32(prefix + ".bias", d) : nullptr;
@@ -247,6 +263,7 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
       ok = ok && up.dense(L.row_out, {r + "layer.out_proj"}, {1.f}, d, d);
       ok = ok && up.ln(L.ln_col, cpre + "layer_norm", d);
       ok = ok && up.dense(L.col_qkv, {cpre + "layer.q_proj", cpre + "layer.k_proj", cpre + "layer.v_proj"}, {qs, 1.f, 1.f}, d, d);
+      if (ok && !strict()) ok = up.headmajor(L.col_qkv_hm, L.col_qkv, cfg.n_heads);
       ok = ok && up.dense(L.col_out, {cpre + "layer.out_proj"}, {1.f}, d, d);
       ok = ok && up.ln(L.ln_ffn, ff + "layer_norm", d);
       ok = ok && up.dense(L.fc1, {ff + "layer.fc1"}, {1.f}, f, d);
@@ -410,11 +427,11 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
 // picks, followed by the LayerNorm kernel at its HBM roofline.  (Normalising inside the GEMM was built in round 3, bit-identical
 // and slower; it left the library in round 4: tools/probes/gemm_ln_fused.hip.)
 int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
-                          float* ws, size_t ws_bytes, int prof_class) {
+                          float* ws, size_t ws_bytes, int prof_class, int colmajor_R, int colmajor_C) {
   const int d = W.N, K = W.K;
   int rc = timed(prof_class, [&] { return OPS(launch_gemm_bf16, stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
   if (rc) return rc;
-  return timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps); });
+  return timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps, false, colmajor_R, colmajor_C); });
 }
 
 // LM head evaluated ONLY at the selected rows: emb_layer_norm_after -> dense -> GELU ->
@@ -642,10 +659,17 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
       });
       if (rc) return rc;
     }
-    if ((rc = resid_gemm_ln(CTX, L.row_out, X, Mi, M, d, L.ln_col, Hh, nullptr, 0, PC_GEMM_OUT))) return rc;                 // x += row_out(ctx); h = LN_col(x)
-    // column attention (q pre-scaled by dh^-0.5 in the weights)
-    if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
-    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_seq_bf16, stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col, pad_tok, cfg.pad_idx, nullptr); }))) return rc;
+    // column block: fused QKV projection + attention when the depth allows (gemm_colattn.hip: the LayerNorm writes its rows in
+    // column-major token order, q / k / v never leave the CU; bit-identical context), else projection + attention kernel
+    const bool col_fused = !pad_tok && colattn_ok(R, d, H) && L.col_qkv_hm.w;
+    if ((rc = resid_gemm_ln(CTX, L.row_out, X, Mi, M, d, L.ln_col, Hh, nullptr, 0, PC_GEMM_OUT, col_fused ? R : 0, col_fused ? C : 0))) return rc;   // x += row_out(ctx); h = LN_col(x)
+    if (col_fused) {
+      if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_colattn, stream, Hh, L.col_qkv_hm.w, L.col_qkv_hm.b, CTX, B, R, C, H, d, d); }))) return rc;
+    } else {
+      // column attention (q pre-scaled by dh^-0.5 in the weights)
+      if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.col_qkv.w, L.col_qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_seq_bf16, stream, QKV, CTX, (int64_t)B * C, R, H, 3 * d, d, d, 2 * d, col, pad_tok, cfg.pad_idx, nullptr); }))) return rc;
+    }
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: nothing but the selected rows is read again -> finish column out-projection and FFN on n_sel rows
       const int64_t Np = round_up64(n_sel, kRowPad);

@@ -209,3 +209,47 @@ def test_generate_single_batch_equals_serial_calls_small_msas():
         valid = one["table"][:, 0] >= 0
         assert np.array_equal(many["sampled_logits"][:, :P][valid], one["sampled_logits"][valid]), j
         assert (many["sampled_tokens"][:, :P][valid] == one["sampled_tokens"][valid]).all() and (many["tokens"] == one["tokens"]).all()
+
+
+_COLFUSE_CHILD = r"""
+import sys, warnings, numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import models, weights
+prec = sys.argv[1]
+cfg = weights.make_config(weights.MSA1B_CONFIG, n_layers=3)
+sd = weights.synthetic_state_dict(cfg, seed=12, std=0.025, embed_std=0.3, ln_jitter=0.1)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    m = models.ESM_MSA1(state_dict=sd, config=cfg, precision=prec).model.to("cuda:0")
+rng = np.random.default_rng(22)
+outs = {}
+for (B, R, C) in [(3, 32, 41), (2, 64, 23), (1, 128, 37), (1, 256, 9), (2, 32, 257), (2, 24, 30)]:
+    tok = rng.integers(4, 24, (B, R, C))
+    tok[rng.random((B, R, C)) < 0.1] = 30
+    tok[rng.random((B, R, C)) < 0.05] = 32
+    tok[..., 0] = 0
+    outs["%%dx%%dx%%d" %% (B, R, C)] = m.forward_logits(tok)
+np.savez(sys.argv[2], **outs)
+"""
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_fused_column_attention_is_bit_identical_with_the_unfused_path(precision, tmp_path):
+    """gemm_colattn.hip (round 4): the column block's QKV projection and attention in one launch -- LayerNorm rows in column-major
+    token order, q / k / v as bf16 planes in LDS, attention_kernel's arithmetic per (sequence, query block) -- must give the logits
+    of the unfused path (projection kernel + attention kernel) BIT FOR BIT at every supported depth (32, 64, 128, 256), with row
+    counts that are not multiples of 256 (pad sequences) and at config 4's width; depth 24 takes the unfused path either way."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for fuse in ("1", "0"):
+        out = tmp_path / ("colfuse%s.npz" % fuse)
+        p = subprocess.run([sys.executable, "-c", _COLFUSE_CHILD % root, precision, str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, PGIBBS_MSA_COLFUSE=fuse), timeout=1200)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        res[fuse] = np.load(out)
+    for k in res["1"].files:
+        assert np.isfinite(res["1"][k]).all(), k
+        assert np.array_equal(res["1"][k].view(np.uint32), res["0"][k].view(np.uint32)), k
