@@ -99,7 +99,7 @@ int pg_engine_synchronize(pg_engine* h) {
   if (!h) return fail(PG_ERR_INVALID, "null engine");
   DeviceGuard g(h->e.device);
   PG_HIP(hipStreamSynchronize(h->e.stream));
-  return PG_OK;
+  return h->e.chain_check();
 }
 int pg_engine_device(const pg_engine* h) { return h ? h->e.device : -1; }
 int pg_engine_set_job_items(pg_engine* h, int64_t job_items) {
@@ -139,7 +139,7 @@ int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, flo
   if ((rc = e.head(nullptr, nullptr, 1, T, M, e.logits.as<float>()))) return rc;
   PG_HIP(hipMemcpyAsync(logits_out, e.logits.p, (size_t)M * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
-  return PG_OK;
+  return e.chain_check();
 }
 
 int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T, const int32_t* d_target_idx, int n_iters,
@@ -183,7 +183,7 @@ int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const in
   if (sampled_tokens && n_draws)
     PG_HIP(hipMemcpyAsync(sampled_tokens, e.d_samp_tok.p, n_draws * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
-  return PG_OK;
+  return e.chain_check();
 }
 
 // ---- ESM-MSA-1b -----------------------------------------------------------------------------

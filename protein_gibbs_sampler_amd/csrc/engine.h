@@ -84,6 +84,12 @@ struct Engine {
   // launch-bound (small) Gibbs loops: one iteration captured as a hipGraph and replayed; the iteration number lives in
   // d_iter on the device, so the same graph serves every iteration
   DevBuf d_iter;
+  // persistent single-chain trunk (chain_trunk.hip): device table of the layers' weight pointers, barrier block, fc2 partials,
+  // and a host-pinned error word the kernel sets when a device-wide barrier timed out
+  PgChainLayerW* chain_layers = nullptr;
+  DevBuf chain_sync, chain_part;
+  unsigned* chain_err = nullptr;
+  int chain_check();                       // after a stream synchronisation: PG_ERR_HIP if chain_err is set
   hipGraphExec_t graph_exec = nullptr;
   std::vector<uint8_t> graph_key;
   int64_t stat_graph_captures = 0, stat_graph_replays = 0;     // pg_engine_get_stat

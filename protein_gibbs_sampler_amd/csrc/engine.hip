@@ -98,8 +98,10 @@ Engine::~Engine() {
   if (device >= 0) (void)hipSetDevice(device);
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
-                    &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk};
+                    &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk,
+                    &chain_sync, &chain_part};
   for (DevBuf* b : bufs) b->release();
+  if (chain_err) (void)hipHostFree(chain_err);
   prof.destroy();
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -271,8 +273,31 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
     }
   }
   if (!ok) return fail(PG_ERR_WEIGHTS, up.err.empty() ? std::string("weight upload failed") : up.err);
+  if (cfg.arch == PG_ARCH_ESM1B && !strict() && OPS(chain_trunk_ok, 32, d, f, cfg.n_heads)) {
+    // the persistent single-chain trunk reads its weights through one device table
+    std::vector<PgChainLayerW> tab(cfg.n_layers);
+    for (int i = 0; i < cfg.n_layers; ++i) {
+      const EsmLayer& L = esm_layers[i];
+      tab[i] = {L.ln1.g, L.ln1.b, L.qkv.w, L.qkv.b, L.out.w, L.out.b, L.ln2.g, L.ln2.b, L.fc1.w, L.fc1.b, L.fc2.w, L.fc2.b};
+    }
+    void* dt = nullptr;
+    PG_HIP(hipMalloc(&dt, tab.size() * sizeof(PgChainLayerW)));
+    owned.push_back(dt);
+    PG_HIP(hipMemcpy(dt, tab.data(), tab.size() * sizeof(PgChainLayerW), hipMemcpyHostToDevice));
+    chain_layers = (PgChainLayerW*)dt;
+    PG_HIP(hipHostMalloc((void**)&chain_err, sizeof(unsigned), hipHostMallocMapped));
+    *chain_err = 0;
+  }
   PG_HIP(hipStreamSynchronize(stream));
   return PG_OK;
+}
+
+int Engine::chain_check() {
+  if (!chain_err || !*chain_err) return PG_OK;
+  *chain_err = 0;
+  if (chain_sync.p) (void)hipMemsetAsync(chain_sync.p, 0, chain_sync.bytes, stream);
+  return fail(PG_ERR_HIP, "single-chain trunk: a device-wide barrier timed out (is another persistent kernel sharing this GPU? "
+                          "PGIBBS_CHAIN_TRUNK=0 selects the per-layer launches)");
 }
 
 // strict precision mode GEMM: one bf16 MFMA GEMM over the K-concatenated split operands (engine.h) reproduces an
@@ -374,15 +399,34 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
                            ln_in_gemm ? nullptr : esm_layers[0].ln1.b, ln_in_gemm ? nullptr : Hh, embed_scale());
   });
   if (rc) return rc;
-  for (int l = 0; l < cfg.n_layers; ++l) {
+  // a single short chain (<= 32 token rows): every layer in ONE persistent launch (chain_trunk.hip; same bits as the per-layer
+  // launches below).  With a selection it stops after the last layer's attention and the pruned tail below finishes on the
+  // selected rows.
+  int l_first = 0;
+  bool attn_done = false;
+  if (ln_in_gemm && chain_layers && !esm_pad_in_batch && T <= 32 && M <= Mi && OPS(chain_trunk_ok, Mi, d, f, cfg.n_heads)) {
+    if ((rc = chain_sync.ensure(OPS(chain_trunk_sync_bytes), stream)) || (rc = chain_part.ensure(OPS(chain_trunk_part_bytes, Mi, d), stream))) return rc;
+    PgChainTrunkArgs ca;
+    ca.layers = chain_layers; ca.n_layers = cfg.n_layers; ca.partial_last = sel_idx ? 1 : 0; ca.B = B; ca.T = T;
+    ca.x = X; ca.qkv = QKV; ca.ctx = CTX; ca.ffn = FFN; ca.part = chain_part.as<float>(); ca.sync = chain_sync.as<unsigned>();
+    ca.err = chain_err; ca.eps = eps;
+    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_chain_trunk, stream, ca, Mi, d); }))) return rc;
+    if (!sel_idx) return PG_OK;
+    l_first = cfg.n_layers - 1;
+    attn_done = true;
+  }
+  for (int l = l_first; l < cfg.n_layers; ++l) {
     const EsmLayer& L = esm_layers[l];
     // Hh holds LN1(x): written by the previous layer's fc2 launch (or the LayerNorm kernel) -- see resid_gemm_ln
-    if (ln_in_gemm) {
+    if (attn_done) {
+      // q | k | v and the attention of this (last) layer were part of the persistent launch
+    } else if (ln_in_gemm) {
       if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_ln_skinny, stream, X, d, L.ln1.g, L.ln1.b, eps, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, 3 * d, EPI_BF16); }))) return rc;
     } else {
       if ((rc = timed(PC_GEMM_QKV, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.qkv.w, L.qkv.b, QKV, Mi, 3 * d, d, d, d, 3 * d, EPI_BF16); }))) return rc;
     }
-    if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_bf16, stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx, L.bias_kv16); }))) return rc;
+    if (!attn_done)
+      if ((rc = timed(PC_ATTN, [&] { return OPS(launch_attention_bf16, stream, QKV, CTX, B, T, cfg.n_heads, 3 * d, d, d, 2 * d, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx, L.bias_kv16); }))) return rc;
     if (sel_idx && l == cfg.n_layers - 1) {
       // last layer: only the selected rows are ever read again -> gather them and finish the layer on n_sel rows
       const int64_t Np = round_up64(n_sel, kRowPad);

@@ -12,6 +12,29 @@ namespace pg {
 // with the inline default flavour)
 }  // namespace pg
 struct PgSeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
+// the persistent single-chain trunk (chain_trunk.hip): one layer's weights as device pointers, and the launch's arguments
+struct PgChainLayerW {
+  const float *ln1_g, *ln1_b;
+  const unsigned short* qkv_w; const float* qkv_b;     // [3 d][d] 16-bit operands (q rows pre-scaled), fp32 bias
+  const unsigned short* out_w; const float* out_b;
+  const float *ln2_g, *ln2_b;
+  const unsigned short* fc1_w; const float* fc1_b;
+  const unsigned short* fc2_w; const float* fc2_b;
+};
+struct PgChainTrunkArgs {
+  const PgChainLayerW* layers;   // device array [n_layers]
+  int n_layers;                  // layers to run, from layers[0]
+  int partial_last;              // 1: the last of them stops after its attention (the pruned tail runs on the selected rows elsewhere)
+  int B, T;                      // chains x tokens, B * T <= 32 token rows
+  float* x;                      // [M][d] fp32 residual stream, in / out
+  unsigned short* qkv;           // [M][3 d]
+  unsigned short* ctx;           // [M][d]
+  unsigned short* ffn;           // [M][4 d]
+  float* part;                   // [4][M][d] fp32: fc2's K-split partial products
+  unsigned* sync;                // chain_trunk_sync_bytes() of zeroed device memory
+  unsigned* err;                 // host-visible word, set to 1 when a device-wide barrier timed out (results are then invalid)
+  float eps;
+};
 namespace pg {
 using SeqLayout = ::PgSeqLayout;
 

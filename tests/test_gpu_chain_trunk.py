@@ -1,0 +1,90 @@
+"""The persistent single-chain trunk (chain_trunk.hip, round 4): every layer of a forward over <= 32 token rows in ONE launch,
+phases separated by device-wide barriers.  Each phase repeats the arithmetic of the kernel it replaces statement for statement, so
+the bar is the strongest one available: the logits -- and the sampled sequences of whole generate() calls -- must be BIT-IDENTICAL
+with the per-layer launches (PGIBBS_CHAIN_TRUNK=0).  The oracle parity of the path itself is covered by the existing config-1 tests
+(test_gpu_engine.py, test_gpu_fullsize_logits.py), which now run through this kernel."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import random, sys, warnings, numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import esm_sampler, models, weights
+prec, out = sys.argv[1], sys.argv[2]
+res = {}
+# full width (d = 1280: the 5-step kernels), 4 layers; and d = 512 / 256 (other instantiations)
+for name, over in (("w1280", dict(n_layers=4)), ("w512", dict(n_layers=3, d_model=512, d_ffn=2048, n_heads=8)),
+                   ("w256", dict(n_layers=2, d_model=256, d_ffn=1024, n_heads=4))):
+    cfg = weights.make_config(weights.ESM1B_CONFIG, **over)
+    sd = weights.synthetic_state_dict(cfg, seed=5, std=0.03, embed_std=0.3, ln_jitter=0.1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wrapped = models.ESM1b(state_dict=sd, config=cfg, precision=prec)
+        s = esm_sampler.ESM_sampler(wrapped, device="gpu")
+    lm = s.model.model
+    rng = np.random.default_rng(3)
+    # one chain of 27 / 32 / 16 / 9 / 1 token rows; two chains of 13; four of 8; three of 5 (15 rows -> one 16-row tile)
+    for (B, T) in [(1, 27), (1, 32), (1, 16), (1, 9), (1, 1), (2, 13), (4, 8), (3, 5), (1, 33)]:
+        tok = rng.integers(4, 24, (B, T))
+        tok[:, 0] = 0
+        tok[rng.random((B, T)) < 0.15] = 32
+        res["%%s_logits_%%dx%%d" %% (name, B, T)] = lm.forward_logits(tok)
+    if name == "w1280":
+        # whole generate() calls (BASELINE config 1's shape): pruned last layer + hipGraph replay around the persistent launch
+        random.seed(7)
+        seqs = []
+        for it in range(3):
+            seqs += s.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", batch_size=1, num_iters=12, burnin=6, mask=True, in_order=False,
+                               num_positions_percent=10, top_k=1, show_progress_bar=False, rollover_from_start=False)
+        seqs += s.generate(2, "MKTAYIAKQR", batch_size=2, num_iters=8, burnin=4, mask=True, in_order=True, num_positions=2, top_k=0,
+                           show_progress_bar=False)
+        res["w1280_generated"] = np.array(seqs)
+        res["w1280_graph_replays"] = np.array([lm.get_stat("graph_replays")])
+np.savez(out, **res)
+"""
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_persistent_trunk_is_bit_identical_with_the_per_layer_launches(precision, tmp_path):
+    res = {}
+    for on in ("1", "0"):
+        out = tmp_path / ("chain%s.npz" % on)
+        p = subprocess.run([sys.executable, "-c", _CHILD % ROOT, precision, str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, PGIBBS_CHAIN_TRUNK=on), timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        res[on] = np.load(out)
+    assert sorted(res["1"].files) == sorted(res["0"].files)
+    n_logits = 0
+    for k in res["1"].files:
+        a, b = res["1"][k], res["0"][k]
+        if "logits" in k:
+            assert np.isfinite(a).all(), k
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, float(np.abs(a - b).max()))
+            n_logits += 1
+        elif k.endswith("generated"):
+            assert list(a) == list(b), k
+    assert n_logits == 27
+    assert int(res["1"]["w1280_graph_replays"][0]) > 0       # the generate() calls replayed a graph holding the persistent launch
+
+
+def test_a_small_grid_gives_the_same_bits(tmp_path):
+    """Fewer workgroups than work units (PGIBBS_CHAIN_TRUNK_GRID=48): every workgroup loops over several units per phase -- the
+    unit loops and their LDS hand-over must not change a bit."""
+    res = {}
+    for grid in ("0", "48"):
+        out = tmp_path / ("grid%s.npz" % grid)
+        p = subprocess.run([sys.executable, "-c", _CHILD % ROOT, "bf16", str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, PGIBBS_CHAIN_TRUNK="1", PGIBBS_CHAIN_TRUNK_GRID=grid), timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        res[grid] = np.load(out)
+    for k in res["0"].files:
+        if "logits" in k:
+            assert np.array_equal(res["0"][k].view(np.uint32), res["48"][k].view(np.uint32)), k
