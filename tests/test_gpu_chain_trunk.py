@@ -17,12 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CHILD = r"""
 import random, sys, warnings, numpy as np
 sys.path.insert(0, %r)
-from protein_gibbs_sampler_amd import esm_sampler, models, weights
+from protein_gibbs_sampler_amd import _cli, esm_sampler, models, weights
 prec, out = sys.argv[1], sys.argv[2]
 res = {}
-# full width (d = 1280: the 5-step kernels), 4 layers; and d = 512 / 256 (other instantiations)
-for name, over in (("w1280", dict(n_layers=4)), ("w512", dict(n_layers=3, d_model=512, d_ffn=2048, n_heads=8)),
-                   ("w256", dict(n_layers=2, d_model=256, d_ffn=1024, n_heads=4))):
+# full width (d = 1280: the 5-step kernels), 4 layers; d = 1024 (the other instantiation); d = 512 (not taken: the per-layer path)
+for name, over in (("w1280", dict(n_layers=4)), ("w1024", dict(n_layers=3, d_model=1024, d_ffn=4096, n_heads=16)),
+                   ("w512", dict(n_layers=2, d_model=512, d_ffn=2048, n_heads=8))):
     cfg = weights.make_config(weights.ESM1B_CONFIG, **over)
     sd = weights.synthetic_state_dict(cfg, seed=5, std=0.03, embed_std=0.3, ln_jitter=0.1)
     with warnings.catch_warnings():
@@ -39,7 +39,7 @@ for name, over in (("w1280", dict(n_layers=4)), ("w512", dict(n_layers=3, d_mode
         res["%%s_logits_%%dx%%d" %% (name, B, T)] = lm.forward_logits(tok)
     if name == "w1280":
         # whole generate() calls (BASELINE config 1's shape): pruned last layer + hipGraph replay around the persistent launch
-        random.seed(7)
+        _cli.seed_everything(7)             # interpreter RNG (position choice) and torch (the draws' Philox seeds)
         seqs = []
         for it in range(3):
             seqs += s.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", batch_size=1, num_iters=12, burnin=6, mask=True, in_order=False,
