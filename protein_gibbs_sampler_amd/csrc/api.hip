@@ -357,7 +357,7 @@ static int forward_logprobs(Engine& e, bool msa, const int32_t* tokens, int B, i
                                   e.d_samp_tok.as<int32_t>(), n_sel, P, e.d_samp_logits.as<float>()))) return rc;
   PG_HIP(hipMemcpyAsync(out, e.d_samp_logits.p, (size_t)n * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
-  return PG_OK;
+  return e.chain_check();
 }
 
 int pg_esm_forward_logprobs(pg_engine* h, const int32_t* tokens, int B, int T, const int32_t* row_of, const int32_t* idx,
