@@ -118,7 +118,7 @@ int pg_engine_get_stat(pg_engine* h, const char* name, int64_t* value) {
 }
 
 // ---- ESM-1b ---------------------------------------------------------------------------------
-int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, float* logits_out) {
+static int esm_forward_logits_once(pg_engine* h, const int32_t* tokens, int B, int T, float* logits_out) {
   if (!h || !tokens || !logits_out) return fail(PG_ERR_INVALID, "pg_esm_forward_logits: null argument");
   Engine& e = h->e;
   if (e.cfg.arch != PG_ARCH_ESM1B && e.cfg.arch != PG_ARCH_ESM1) return fail(PG_ERR_INVALID, "engine was not built for an ESM-1b / ESM-1 architecture");
@@ -141,6 +141,20 @@ int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, flo
   PG_HIP(hipStreamSynchronize(e.stream));
   return e.chain_check();
 }
+// The persistent single-chain trunk is an optimistic fast path: when one of its barriers timed out (Engine::chain_check) the
+// call's inputs are still intact in the caller's buffers, so it runs once more, now on the per-layer launches.
+#define PG_RETRY_WITHOUT_CHAIN_TRUNK(h, call)                          \
+  do {                                                                \
+    int rc_ = (call);                                                 \
+    if (rc_ && (h) && (h)->e.chain_retry) {                           \
+      (h)->e.chain_retry = false;                                     \
+      rc_ = (call);                                                   \
+    }                                                                 \
+    return rc_;                                                       \
+  } while (0)
+int pg_esm_forward_logits(pg_engine* h, const int32_t* tokens, int B, int T, float* logits_out) {
+  PG_RETRY_WITHOUT_CHAIN_TRUNK(h, esm_forward_logits_once(h, tokens, B, T, logits_out));
+}
 
 int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T, const int32_t* d_target_idx, int n_iters,
                             int P, const pg_sample_params* params, float* d_sampled_logits, int32_t* d_sampled_tokens) {
@@ -152,8 +166,8 @@ int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T,
   return h->e.esm_gibbs_device(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
 }
 
-int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,
-                     const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
+static int esm_gibbs_run_once(pg_engine* h, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,
+                              const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
   if (!h || !tokens_inout || (!target_idx && P > 0 && n_iters > 0)) return fail(PG_ERR_INVALID, "pg_esm_gibbs_run: null argument");
   int rc = check_params(params, h->e.cfg.vocab);
   if (rc) return rc;
@@ -177,13 +191,21 @@ int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const in
                           sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
                           sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
   if (rc) return rc;
+  if (e.chain_err) {                       // before the caller's token buffer (input AND output) is overwritten
+    PG_HIP(hipStreamSynchronize(e.stream));
+    if ((rc = e.chain_check())) return rc;
+  }
   PG_HIP(hipMemcpyAsync(tokens_inout, e.d_tokens.p, tok_bytes, hipMemcpyDeviceToHost, e.stream));
   if (sampled_logits && n_draws)
     PG_HIP(hipMemcpyAsync(sampled_logits, e.d_samp_logits.p, n_draws * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
   if (sampled_tokens && n_draws)
     PG_HIP(hipMemcpyAsync(sampled_tokens, e.d_samp_tok.p, n_draws * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
-  return e.chain_check();
+  return PG_OK;
+}
+int pg_esm_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,
+                     const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens) {
+  PG_RETRY_WITHOUT_CHAIN_TRUNK(h, esm_gibbs_run_once(h, tokens_inout, B, T, target_idx, n_iters, P, params, sampled_logits, sampled_tokens));
 }
 
 // ---- ESM-MSA-1b -----------------------------------------------------------------------------
@@ -366,7 +388,7 @@ int pg_esm_forward_logprobs(pg_engine* h, const int32_t* tokens, int B, int T, c
   if (h->e.cfg.arch != PG_ARCH_ESM1B && h->e.cfg.arch != PG_ARCH_ESM1) return fail(PG_ERR_INVALID, "engine was not built for an ESM-1b / ESM-1 architecture");
   if (B < 0 || T < 1 || n_sel < 0 || P < 0) return fail(PG_ERR_INVALID, "bad shape");
   if (T > h->e.cfg.max_positions) return fail(PG_ERR_INVALID, "sequence longer than the learned position table");
-  return forward_logprobs(h->e, false, tokens, B, 1, T, row_of, idx, targets, n_sel, P, out);
+  PG_RETRY_WITHOUT_CHAIN_TRUNK(h, forward_logprobs(h->e, false, tokens, B, 1, T, row_of, idx, targets, n_sel, P, out));
 }
 
 int pg_msa_forward_logprobs(pg_engine* h, const int32_t* tokens, int B, int R, int C, const int32_t* row_of,

@@ -89,7 +89,11 @@ struct Engine {
   PgChainLayerW* chain_layers = nullptr;
   DevBuf chain_sync, chain_part;
   unsigned* chain_err = nullptr;
-  int chain_check();                       // after a stream synchronisation: PG_ERR_HIP if chain_err is set
+  // after a stream synchronisation: PG_ERR_HIP if chain_err is set.  The kernel is then switched off for the rest of this engine's
+  // life (the device is evidently shared with another persistent grid) and chain_retry tells the host-buffer entry points, whose
+  // inputs are intact, to run the call again on the per-layer launches
+  int chain_check();
+  bool chain_disabled = false, chain_retry = false;
   hipGraphExec_t graph_exec = nullptr;
   std::vector<uint8_t> graph_key;
   int64_t stat_graph_captures = 0, stat_graph_replays = 0;     // pg_engine_get_stat

@@ -296,8 +296,14 @@ int Engine::chain_check() {
   if (!chain_err || !*chain_err) return PG_OK;
   *chain_err = 0;
   if (chain_sync.p) (void)hipMemsetAsync(chain_sync.p, 0, chain_sync.bytes, stream);
+  if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; graph_key.clear(); }   // it holds the persistent launch
+  if (!chain_disabled)
+    fprintf(stderr, "pgibbs: a device-wide barrier of the persistent single-chain trunk timed out (another persistent grid on this GPU?); "
+                    "this engine uses the per-layer launches from now on\n");
+  chain_disabled = true;
+  chain_retry = true;
   return fail(PG_ERR_HIP, "single-chain trunk: a device-wide barrier timed out (is another persistent kernel sharing this GPU? "
-                          "PGIBBS_CHAIN_TRUNK=0 selects the per-layer launches)");
+                          "PGIBBS_CHAIN_TRUNK=0 selects the per-layer launches); the results of this call are invalid");
 }
 
 // strict precision mode GEMM: one bf16 MFMA GEMM over the K-concatenated split operands (engine.h) reproduces an
@@ -404,13 +410,18 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
   // selected rows.
   int l_first = 0;
   bool attn_done = false;
-  if (ln_in_gemm && chain_layers && !esm_pad_in_batch && T <= 32 && M <= Mi && OPS(chain_trunk_ok, Mi, d, f, cfg.n_heads)) {
+  if (ln_in_gemm && chain_layers && !chain_disabled && !esm_pad_in_batch && T <= 32 && M <= Mi && OPS(chain_trunk_ok, Mi, d, f, cfg.n_heads)) {
     if ((rc = chain_sync.ensure(OPS(chain_trunk_sync_bytes), stream)) || (rc = chain_part.ensure(OPS(chain_trunk_part_bytes, Mi, d), stream))) return rc;
     PgChainTrunkArgs ca;
     ca.layers = chain_layers; ca.n_layers = cfg.n_layers; ca.partial_last = sel_idx ? 1 : 0; ca.B = B; ca.T = T;
     ca.x = X; ca.qkv = QKV; ca.ctx = CTX; ca.ffn = FFN; ca.part = chain_part.as<float>(); ca.sync = chain_sync.as<unsigned>();
     ca.err = chain_err; ca.eps = eps;
     if ((rc = timed(PC_GEMM, [&] { return OPS(launch_chain_trunk, stream, ca, Mi, d); }))) return rc;
+    {   // test hook: PGIBBS_CHAIN_TRUNK_FAULT=n makes the n-th persistent launch of the process report a barrier timeout
+      static const int fault_at = [] { const char* e = getenv("PGIBBS_CHAIN_TRUNK_FAULT"); return e ? atoi(e) : 0; }();
+      static int launches = 0;
+      if (fault_at > 0 && ++launches == fault_at) *chain_err = 1;
+    }
     if (!sel_idx) return PG_OK;
     l_first = cfg.n_layers - 1;
     attn_done = true;

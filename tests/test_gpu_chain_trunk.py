@@ -88,3 +88,48 @@ def test_a_small_grid_gives_the_same_bits(tmp_path):
     for k in res["0"].files:
         if "logits" in k:
             assert np.array_equal(res["0"][k].view(np.uint32), res["48"][k].view(np.uint32)), k
+
+
+_FAULT_CHILD = r"""
+import sys, warnings, numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import _cli, esm_sampler, models, weights
+cfg = weights.make_config(weights.ESM1B_CONFIG, n_layers=3)
+sd = weights.synthetic_state_dict(cfg, seed=5, std=0.03, embed_std=0.3, ln_jitter=0.1)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    s = esm_sampler.ESM_sampler(models.ESM1b(state_dict=sd, config=cfg), device="gpu")
+lm = s.model.model
+rng = np.random.default_rng(3)
+res = {}
+_cli.seed_everything(7)
+for c in range(4):
+    tok = rng.integers(4, 24, (1, 27)); tok[:, 0] = 0
+    res["logits%%d" %% c] = lm.forward_logits(tok)
+    res["gen%%d" %% c] = np.array(s.generate(1, "MEPAATGQEAEECAHSGRGEAWEEV", batch_size=1, num_iters=8, burnin=4, mask=True, in_order=False,
+                                             num_positions_percent=10, top_k=1, show_progress_bar=False))
+np.savez(sys.argv[1], **res)
+"""
+
+
+@pytest.mark.parametrize("fault_at", [1, 2, 3, 5])   # 1st forward; eager iteration 0; graph capture; a later forward
+def test_a_barrier_timeout_falls_back_to_the_per_layer_launches(fault_at, tmp_path):
+    """The persistent launch is an optimistic fast path: when it reports a barrier timeout (two persistent grids sharing a GPU can
+    starve each other; here the n-th launch is made to report one, PGIBBS_CHAIN_TRUNK_FAULT) the host-buffer entry points run the
+    call again on the per-layer launches and the engine stays on them -- same results as a run that never used the kernel, one
+    warning on stderr, no error."""
+    res = {}
+    for name, env in (("fault", dict(PGIBBS_CHAIN_TRUNK="1", PGIBBS_CHAIN_TRUNK_FAULT=str(fault_at))), ("ref", dict(PGIBBS_CHAIN_TRUNK="0"))):
+        out = tmp_path / (name + ".npz")
+        p = subprocess.run([sys.executable, "-c", _FAULT_CHILD % ROOT, str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        if name == "fault":
+            assert p.stderr.count("uses the per-layer launches from now on") == 1, p.stderr[-2000:]
+        res[name] = np.load(out)
+    for k in res["ref"].files:
+        a, b = res["fault"][k], res["ref"][k]
+        if k.startswith("logits"):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), k
+        else:
+            assert list(a) == list(b), k
