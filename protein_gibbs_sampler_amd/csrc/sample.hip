@@ -69,14 +69,19 @@ struct SampleArgs {
 
 // logits addressing: compact [n_sel*P][V] (engine path: LM head evaluated only at the sampled rows),
 // or full [n_rows][width][V] (plug-in models).
+// One WAVE per draw (round 4; it was one thread per draw -- a 32 x 32 rank loop and 32 exponentials in a single lane, 42 us
+// however few draws there were, 3 % of a config-1 iteration): lane j holds valid entry j.  Every floating-point operation and its
+// order is the one-thread form's (the cumulative sums are accumulated in rank order, one after the other, in a value all lanes
+// hold), so the draws are the same bit for bit.
 __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restrict__ tokens, int width,
                                                               const float* __restrict__ logits, int V, int compact,
                                                               const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ row_map, int64_t n_sel, int P,
                                                               SampleArgs a, int32_t* __restrict__ sampled_tokens,
                                                               const int32_t* __restrict__ d_iter) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_sel * P) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= n_sel * P) return;   // wave-uniform
   if (d_iter) {               // graph replay: the iteration number AND the sampling parameters live on the device, so one
     const int it = *d_iter;   // captured graph serves every iteration of every call with this shape (launch_graph_state)
     a = *(const SampleArgs*)(d_iter + kGraphArgsOffset);
@@ -88,12 +93,12 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
   const int slot = (int)(i - s * P);
   const int raw = idx[i];
   if (raw < 0) {
-    if (sampled_tokens) sampled_tokens[i] = -1;
+    if (sampled_tokens && lane == 0) sampled_tokens[i] = -1;
     return;
   }
   const int pos = raw & 0x3fffffff;
   if (pos >= width) {          // out-of-range position (the host entry points reject these; *_device callers are guarded here)
-    if (sampled_tokens) sampled_tokens[i] = -1;
+    if (sampled_tokens && lane == 0) sampled_tokens[i] = -1;
     return;
   }
   const int64_t trow = row_map ? (int64_t)row_map[s] : s;
@@ -102,58 +107,53 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
   const int nv = a.n_valid;
   int k = a.top_k;
   if (a.sample || k <= 0 || k > nv) k = nv;
-  float sv[32];
+  // this lane's entry of the valid list (static indices into the by-value struct: no private-memory copy)
+  int my_valid = 0;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    float v = 0.f;
-    if (j < nv) {
-      v = row[a.valid_idx[j]];
-      if (a.use_temp) v = v / a.temperature;
-    }
-    sv[j] = v;
+  for (int m = 0; m < 32; ++m)
+    if (m == lane) my_valid = a.valid_idx[m];
+  const bool mine = lane < nv;
+  float v = 0.f;
+  if (mine) {
+    v = row[my_valid];
+    if (a.use_temp) v = v / a.temperature;
   }
   // stable descending rank of every valid entry
-  float ev[32];   // values in rank order
-  int ei[32];     // valid-list position in rank order
+  int rank = 0;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    if (j < nv) {
-      int rank = 0;
-#pragma unroll
-      for (int m = 0; m < 32; ++m)
-        if (m < nv) rank += (sv[m] > sv[j]) || (sv[m] == sv[j] && m < j);
-      // scatter by rank (rank is a permutation of 0..nv-1)
-#pragma unroll
-      for (int m = 0; m < 32; ++m)
-        if (m == rank) { ev[m] = sv[j]; ei[m] = j; }
+  for (int m = 0; m < 32; ++m) {
+    if (m < nv) {                                      // wave-uniform
+      const float vm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), m));
+      rank += (vm > v) || (vm == v && m < lane);
     }
   }
-  const float top = ev[0];
-  float cum[32];
-  float acc = 0.f;
+  // lane r receives the value and the valid-list position of the entry with rank r (rank is a permutation of 0..nv-1)
+  const int dst = (mine ? rank : lane) * 4;            // idle lanes send to themselves
+  const float ev = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, v)));
+  const int ei = __builtin_amdgcn_ds_permute(dst, lane);
+  const float top = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ev), 0));
+  const float e = lane < k ? pg_exp(ev - top) : 0.f;
+  float acc = 0.f, cum = 0.f;
 #pragma unroll
   for (int r = 0; r < 32; ++r) {
-    if (r < k) {
-      const float e = pg_exp(ev[r] - top);
-      acc = (r == 0) ? e : acc + e;
-      cum[r] = acc;
+    if (r < k) {                                       // wave-uniform
+      const float er = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), r));
+      acc = (r == 0) ? er : acc + er;
+      if (lane == r) cum = acc;
     }
   }
   uint32_t w0;
   philox4x32_10(a.row_id_base + (uint32_t)s, a.iter, (uint32_t)slot, a.stream, a.seed_lo, a.seed_hi, w0);
   const float u = (float)(w0 >> 8) * 0x1.0p-24f;
   const float t = u * acc;
-  int jsel = k - 1;
-#pragma unroll
-  for (int r = 31; r >= 0; --r)
-    if (r < k && cum[r] > t) jsel = r;
-  int pick = 0;
-#pragma unroll
-  for (int r = 0; r < 32; ++r)
-    if (r == jsel) pick = ei[r];
-  const int tok = a.valid_idx[pick];
-  if (sampled_tokens) sampled_tokens[i] = tok;
-  if (!(raw & 0x40000000)) tokens[trow * width + pos] = tok;
+  const unsigned long long hit = __ballot(lane < k && cum > t);
+  const int jsel = hit ? (int)__builtin_ctzll(hit) : k - 1;
+  const int pick = __builtin_amdgcn_readlane(ei, jsel);
+  const int tok = __builtin_amdgcn_readlane(my_valid, pick);
+  if (lane == 0) {
+    if (sampled_tokens) sampled_tokens[i] = tok;
+    if (!(raw & 0x40000000)) tokens[trow * width + pos] = tok;
+  }
 }
 
 __global__ __launch_bounds__(256) void mask_scatter_kernel(int32_t* __restrict__ tokens, int width,
@@ -261,8 +261,8 @@ int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const fl
   const int64_t n = n_sel * P;
   if (n == 0) return 0;
   const SampleArgs a = make_sample_args(p, iteration);
-  hipLaunchKernelGGL(sample_writeback_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, width, logits, V,
-                     compact, idx, row_map, n_sel, P, a, sampled_tokens, d_iter);
+  hipLaunchKernelGGL(sample_writeback_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, tokens, width, logits, V,
+                     compact, idx, row_map, n_sel, P, a, sampled_tokens, d_iter);      // one wave per draw
   PG_HIP(hipGetLastError());
   return 0;
 }
