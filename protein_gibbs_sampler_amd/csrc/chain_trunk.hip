@@ -33,8 +33,11 @@
 // (40 feature pairs x 4 K-splits; the workgroup that completes a pair's fourth partial adds the four, in split order, to the
 // residual stream -- "last arriver reduces", deterministic); attention one wave per (chain, head, 16-query block).
 //
-// A barrier that does not open within 50 ms (two persistent grids sharing one GPU could starve each other) sets an error word
-// instead of hanging the device; the engine reports it (PG_ERR_HIP) after the call.
+// All workgroups must be resident at once (the barriers spin).  Alone on the device they are: one 8-wave workgroup per CU.  Two
+// persistent grids sharing one GPU -- two processes sampling single chains -- can each hold half of the CUs and starve each other
+// (measured: 21 timeouts in 150 calls), so a barrier that does not open within 50 ms sets a host-visible error word instead of
+// hanging the device, every later wait of that workgroup is skipped, and the engine (Engine::chain_check) switches to the per-layer
+// launches for good and re-runs the call from the caller's intact inputs.
 #include <algorithm>
 
 #include "gemm_epilogue.h"
