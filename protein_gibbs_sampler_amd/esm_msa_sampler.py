@@ -55,6 +55,9 @@ class ESM_MSA_sampler():
         self.shard_over_ranks = False    # opt-in (or PGIBBS_SHARD_OVER_RANKS=1): generate() / generate_single_batch() split ONE job's MSAs over the torch.distributed ranks
 
     def untokenize_batch(self, batch):
+        if hasattr(batch, "numpy") and getattr(batch, "ndim", 0) == 3:       # a [B, R, C] token tensor: one table lookup per row
+            arr = batch.numpy()
+            return self.model.alphabet.decode_rows(arr[:, :, 1:].reshape(-1, arr.shape[2] - 1))
         if hasattr(batch, "tolist"):
             batch = batch.tolist()
         out_batch = list()
@@ -187,7 +190,8 @@ class ESM_MSA_sampler():
             return ["".join(self.model.alphabet.get_tok(int(v)) for v in full[j, 1:jobs[j]["batch"].shape[2]]) for j in range(n)]
         if not self.record:
             self.last_run = []
-        return [self.untokenize_batch(job["batch"])[target_index] for job in jobs]
+        # == untokenize_batch(batch)[target_index] (reference :147) without spelling out the other rows of the alignment
+        return [self.untokenize_batch(job["batch"][:, job["tr"]:job["tr"] + 1])[0] for job in jobs]
 
     # ---- whole-MSA resampling (reference :151-253) ------------------------------------------------
     def generate(self, n_samples, seed_msa, batch_size=1, in_order=False, max_len=None, leader_length=0,

@@ -95,6 +95,9 @@ class ESM_sampler():
     def untokenize_batch(self, batch, bos, eos):
         start_offset = 1 if bos else 0
         end_offset = -1 if eos else 0
+        if hasattr(batch, "numpy") and getattr(batch, "ndim", 0) == 2:       # a [B, T] token tensor: one table lookup per row
+            arr = batch.numpy()
+            return self.model.alphabet.decode_rows(arr[:, start_offset:arr.shape[1] + end_offset])
         if hasattr(batch, "tolist"):
             batch = batch.tolist()
         return ["".join([self.model.alphabet.get_tok(seq[i]) for i in range(0 + start_offset, len(seq) + end_offset)])
