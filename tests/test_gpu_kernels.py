@@ -99,7 +99,10 @@ def test_layernorm(M, d):
 
 
 @pytest.mark.parametrize("B,T,H", [(2, 27, 2), (3, 258, 2), (1, 16, 1), (2, 100, 3), (1, 200, 1), (1, 300, 2), (1, 513, 1),
-                                   (1, 577, 1), (2, 700, 2), (1, 1024, 1)])
+                                   (1, 577, 1), (2, 700, 2), (1, 1024, 1),
+                                   # 4 n + 1 query blocks (one wave alone in the last round) at every tile width of the ladder
+                                   (2, 65, 1), (2, 129, 2), (1, 144, 1), (2, 193, 1), (1, 208, 2), (2, 257, 2), (1, 272, 1), (1, 321, 1),
+                                   (1, 385, 2), (1, 449, 1), (1, 464, 1), (1, 528, 1)])
 def test_attention(B, T, H):
     rng = np.random.default_rng(T)
     d = H * 64
@@ -116,3 +119,4 @@ def test_attention(B, T, H):
     # P and the output are rounded to bf16 (8-bit mantissa): abs error ~ 2^-8 * |ctx|
     assert np.abs(ctx - ref).max() < 2.5e-2, np.abs(ctx - ref).max()
     assert np.abs(ctx - ref).mean() < 3e-3
+
