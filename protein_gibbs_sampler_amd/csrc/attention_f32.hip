@@ -16,8 +16,9 @@
 
 PG_OPS_BEGIN
 
-// One thread's 64 context values of head h -> bf16 into the token's context row.  split_d > 0: the row is the strict mode's
-// split operand (3 * split_d values, groups of 32 columns [lo | hi | hi]; elementwise.hip store_row_bf16).
+// One thread's 64 context values of head h -> bf16 into the token's context row.  split_d != 0: the row is the strict mode's
+// split operand (3 * |split_d| values, groups of 32 columns [lo | hi | hi]; elementwise.hip store_row_bf16); split_d < 0: without
+// the duplicate hi block -- the out-projection that reads the rows is the fused three-product kernel (gemm_split3_fused).
 __device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf16_t* row, int h, int split_d) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -33,7 +34,7 @@ __device__ __forceinline__ void store_ctx64(const float (&o)[64], float inv, bf1
       bf16_t* g = row + (2 * h + (i >> 3)) * 96 + (i & 7) * 4;       // columns h*64 + 4i .. +3
       *(uint2*)g = r;
       *(uint2*)(g + 32) = p;
-      *(uint2*)(g + 64) = p;
+      if (split_d > 0) *(uint2*)(g + 64) = p;
     }
   }
 }
@@ -202,7 +203,7 @@ struct SplitAttn {
         bf16_t* g = row + (2 * h + (db >> 1)) * 96 + (db & 1) * 16 + fq * 4;
         *(uint2*)g = r;
         *(uint2*)(g + 32) = p;
-        *(uint2*)(g + 64) = p;
+        if (split_d > 0) *(uint2*)(g + 64) = p;
       }
     }
   }

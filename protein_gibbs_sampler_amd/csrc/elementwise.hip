@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
   ln_inplace(v, nch4, lane, d, eps, gamma, beta);
-  store_row_bf16(h + (size_t)row * d * (split3 ? 3 : 1), v, nch4, lane, split3);
+  store_row_bf16(h + (size_t)row * d * (split3 ? 3 : 1), v, nch4, lane, split3, split3 != 2);       // split3 == 2: no duplicate hi block
 }
 
 // The same with the output rows in COLUMN-MAJOR token order: token row (b*R + r)*C + c -> operand row (b*C + c)*R + r, so that a
@@ -344,7 +344,7 @@ int launch_embed_ln(hipStream_t s, const int32_t* tokens, const float* embed, co
 }
 
 int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, const float* beta, bf16_t* h, int64_t M,
-                          int d, float eps, bool split3, int colmajor_R, int colmajor_C) {
+                          int d, float eps, bool split3, int colmajor_R, int colmajor_C, bool split3_dup) {
   if (d % 4 || d > kMaxCh * 256) return fail(1, "layernorm: d must be a multiple of 4 and <= 2048");
   if (M == 0) return 0;
   if (colmajor_R > 0) {
@@ -353,7 +353,7 @@ int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, con
     PG_HIP(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, split3 ? 1 : 0, M, d, eps);
+  hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, split3 ? (split3_dup ? 1 : 2) : 0, M, d, eps);
   PG_HIP(hipGetLastError());
   return 0;
 }

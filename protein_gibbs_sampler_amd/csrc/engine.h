@@ -105,7 +105,8 @@ struct Engine {
   // out[Mp][N] fp32 (=|+=) X.W^T + b with X = xh + xl, W = wh + wl as ONE bf16 GEMM over K' = 3K:
   // [xl | xh | xh] . [wh | wl | wh]^T = xl.wh + xh.wl + xh.wh  (the dropped xl.wl term is ~2^-17 relative)
   int dense3(const bf16_t* x3, const DenseW& W, float* out, int Mp, bool accumulate);
-  int dense3_gelu(const bf16_t* x3, const DenseW& W, int Mp);      // fc1: ffn (operand rows) = split3(gelu(.))
+  int dense3_gelu(const bf16_t* x3, const DenseW& W, int Mp, const DenseW* next = nullptr);   // fc1: ffn (operand rows) = split3(gelu(.)); next = the projection that reads them
+  bool dense3_wants_dup(const DenseW& W, int Mp, bool gelu = false) const;   // does this projection read the duplicate hi block of its operand rows?
   Prof prof;
 
   ~Engine();

@@ -321,14 +321,27 @@ int Engine::sel_gemm_rows(int64_t n_sel, int64_t Np) const {
   return (batch_rows > 2048 && r < 64) ? 64 : r;
 }
 
+// The split operand rows are [lo | hi | hi] per 32 columns; the fused three-product kernel reads [lo | hi] only (gemm_w16.hip), the
+// plain kernels over K' = 3K all three blocks.  A producer (LayerNorm, fc1's epilogue) skips the duplicate block -- a fifth of a
+// LayerNorm's traffic, a third of fc1's stores -- exactly when its consumer is the fused kernel.
+bool Engine::dense3_wants_dup(const DenseW& W, int Mp, bool gelu) const {
+  static const int nodup = [] { const char* e = getenv("PGIBBS_SPLIT3_NODUP"); return e ? atoi(e) : 1; }();
+  if (!nodup) return true;
+  if (gelu && W.N % 256 == 0 && Mp % 256 == 0) return false;          // dense3_gelu's fused form: always the 16-wave kernel
+  return !gemm_split3_fused(Mp, W.N, W.K, EPI_F32);
+}
+
 // strict fc1: ffn = split3(gelu(x3 . W^T + b)).  Fused into the GEMM's epilogue when the 16-wave kernel can take the shape
 // (d_ffn a multiple of 256), else an fp32 GEMM followed by the GELU-and-split pass.  The fused epilogue evaluates the GELU
 // with the degree-5 fit of log2 Phi(-|x|) that the bf16 mode uses (abs error 3.2e-6, below the 2^-17 relative error of the
 // split products at |x| ~ 1; 9 instead of 22 issue slots per element in an epilogue that nothing overlaps), the pass with erff.
 // Full-size strict logits against the oracle with this: ESM-1b 5.8e-4, MSA-1b 4.6e-4 (5.7e-4 / 4.0e-4 with erff).
-int Engine::dense3_gelu(const bf16_t* x3, const DenseW& W, int Mp) {
-  if (W.N % 256 == 0 && Mp % 256 == 0)
-    return timed(PC_GEMM, [&] { return launch_gemm_split3(stream, x3, W.w, W.b, ffn.as<bf16_t>(), Mp, W.N, W.K, 3 * W.N, EPI_SPLIT3_GELU); });
+int Engine::dense3_gelu(const bf16_t* x3, const DenseW& W, int Mp, const DenseW* next) {
+  if (W.N % 256 == 0 && Mp % 256 == 0) {
+    // the rows leave without their duplicate hi block when the projection that reads them (fc2) never looks at it
+    const int epi = next && !dense3_wants_dup(*next, Mp) ? EPI_SPLIT2_GELU : EPI_SPLIT3_GELU;
+    return timed(PC_GEMM, [&] { return launch_gemm_split3(stream, x3, W.w, W.b, ffn.as<bf16_t>(), Mp, W.N, W.K, 3 * W.N, epi); });
+  }
   int rc = ffn_f32.ensure((size_t)Mp * W.N * 4, stream);       // fp32 intermediate of the unfused form only
   if (rc || (rc = dense3(x3, W, ffn_f32.as<float>(), Mp, false))) return rc;
   return timed(PC_LN, [&] { return launch_split3_bf16(stream, ffn_f32.as<float>(), ffn.as<bf16_t>(), Mp, W.N, 1.f, true, false); });
@@ -370,12 +383,12 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     const SeqLayout chain = {1, T, 0, 1};
     for (int l = 0; l < cfg.n_layers; ++l) {
       const EsmLayer& L = esm_layers[l];
-      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln1.g, L.ln1.b, h.as<bf16_t>(), M, d, eps, true, 0, 0, dense3_wants_dup(L.qkv, Mi)); }))) return rc;
       if ((rc = dense3(h.as<bf16_t>(), L.qkv, QKVf, Mi, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), d, B, T, cfg.n_heads, 3 * d, 3 * d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx, L.bias_kv32); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, ctx.as<bf16_t>(), dense3_wants_dup(L.out, Mi) ? d : -d, B, T, cfg.n_heads, 3 * d, 3 * d, d, 2 * d, chain, esm_pad_in_batch ? d_tok : nullptr, cfg.pad_idx, L.bias_kv32); }))) return rc;
       if ((rc = dense3(ctx.as<bf16_t>(), L.out, X, Mi, true))) return rc;
-      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, true); }))) return rc;
-      if ((rc = dense3_gelu(h.as<bf16_t>(), L.fc1, Mi))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, X, L.ln2.g, L.ln2.b, h.as<bf16_t>(), M, d, eps, true, 0, 0, dense3_wants_dup(L.fc1, Mi, true)); }))) return rc;
+      if ((rc = dense3_gelu(h.as<bf16_t>(), L.fc1, Mi, &L.fc2))) return rc;
       if ((rc = dense3(ffn.as<bf16_t>(), L.fc2, X, Mi, true))) return rc;
     }
     return PG_OK;
@@ -661,16 +674,16 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     const SeqLayout colS = {C, R * C, 1, C};
     for (int l = 0; l < cfg.n_layers; ++l) {
       const MsaLayer& L = msa_layers[l];
-      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_row.g, L.ln_row.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_row.g, L.ln_row.b, H3, M, d, eps2, true, 0, 0, dense3_wants_dup(L.row_qkv, Mi2)); }))) return rc;
       if ((rc = dense3(H3, L.row_qkv, QKVf, Mi2, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_f32(stream, QKVf, scores.as<float>(), C3, d, B, R, C, H, 3 * d, 3 * d, d, 2 * d, row_scale, pad_tok, cfg.pad_idx); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_msa_row_attention_f32(stream, QKVf, scores.as<float>(), C3, dense3_wants_dup(L.row_out, Mi2) ? d : -d, B, R, C, H, 3 * d, 3 * d, d, 2 * d, row_scale, pad_tok, cfg.pad_idx); }))) return rc;
       if ((rc = dense3(C3, L.row_out, Xs, Mi2, true))) return rc;
-      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_col.g, L.ln_col.b, H3, M, d, eps2, true); }))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_col.g, L.ln_col.b, H3, M, d, eps2, true, 0, 0, dense3_wants_dup(L.col_qkv, Mi2)); }))) return rc;
       if ((rc = dense3(H3, L.col_qkv, QKVf, Mi2, false))) return rc;
-      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, C3, d, (int64_t)B * C, R, H, 3 * d, 3 * d, d, 2 * d, colS, pad_tok, cfg.pad_idx); }))) return rc;
+      if ((rc = timed(PC_ATTN, [&] { return launch_attention_f32(stream, QKVf, C3, dense3_wants_dup(L.col_out, Mi2) ? d : -d, (int64_t)B * C, R, H, 3 * d, 3 * d, d, 2 * d, colS, pad_tok, cfg.pad_idx); }))) return rc;
       if ((rc = dense3(C3, L.col_out, Xs, Mi2, true))) return rc;
-      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_ffn.g, L.ln_ffn.b, H3, M, d, eps2, true); }))) return rc;
-      if ((rc = dense3_gelu(H3, L.fc1, Mi2))) return rc;
+      if ((rc = timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, Xs, L.ln_ffn.g, L.ln_ffn.b, H3, M, d, eps2, true, 0, 0, dense3_wants_dup(L.fc1, Mi2, true)); }))) return rc;
+      if ((rc = dense3_gelu(H3, L.fc1, Mi2, &L.fc2))) return rc;
       if ((rc = dense3(ffn.as<bf16_t>(), L.fc2, Xs, Mi2, true))) return rc;
     }
     return PG_OK;

@@ -936,13 +936,18 @@ int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
 // Strict-mode projection on split operands (X3 [M][3K], W3 [N][3K]; K = logical depth): the fused three-product kernel when its
 // 256 x 256 tiles fill the chip, else the plain GEMM over K' = 3K -- same summation order, bit-identical results
 // (PGIBBS_SPLIT3_FUSED=0 forces the plain form; tests compare the two).
+// Will launch_gemm_split3 take the fused kernel for this shape?  The fused kernel (and its tail tiles) read only the [lo | hi]
+// blocks of an activation row's groups, the plain kernels all three: a producer may leave the duplicate hi block unwritten
+// exactly when this says yes for its consumer (Engine: LayerNorm rows, fc1's EPI_SPLIT2_GELU rows).
+bool gemm_split3_fused(int M, int N, int K, int epi) {
+  static const int fused = [] { const char* e = getenv("PGIBBS_SPLIT3_FUSED"); return e ? atoi(e) : 1; }();
+  const bool ok256 = M % 256 == 0 && N % 256 == 0 && K % 32 == 0 && M >= 256;
+  return ok256 && (epi == EPI_SPLIT3_GELU || epi == EPI_SPLIT2_GELU || (fused && (long)(M / 256) * (N / 256) >= 128));
+}
 int launch_gemm_split3(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K, int ldo,
                        int epi) {
-  static const int fused = [] { const char* e = getenv("PGIBBS_SPLIT3_FUSED"); return e ? atoi(e) : 1; }();
-  const bool ok256 = M % 256 == 0 && N % 256 == 0 && K % 32 == 0;
-  if (ok256 && (epi == EPI_SPLIT3_GELU || (fused && (long)(M / 256) * (N / 256) >= 128)))
-    return launch_gemm_split3_w16(s, X3, W3, bias, out, M, N, K, ldo, epi);
-  if (epi == EPI_SPLIT3_GELU) return fail(1, "gemm: split-operand epilogue needs M, N multiples of 256");
+  if (gemm_split3_fused(M, N, K, epi)) return launch_gemm_split3_w16(s, X3, W3, bias, out, M, N, K, ldo, epi);
+  if (epi == EPI_SPLIT3_GELU || epi == EPI_SPLIT2_GELU) return fail(1, "gemm: split-operand epilogue needs M, N multiples of 256");
   return launch_gemm_bf16(s, X3, W3, bias, out, M, N, 3 * K, 3 * K, 3 * K, ldo, epi);
 }
 #endif  // !PG_F16

@@ -154,7 +154,7 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
   for (int j = 0; j < TM; ++j) {
     const int m_loc = (mi0 + j) * 16 + fr;
     float v0 = acc[j][0] + b4.x, v1 = acc[j][1] + b4.y, v2 = acc[j][2] + b4.z, v3 = acc[j][3] + b4.w;
-    if (EPI == EPI_SPLIT3_GELU) {
+    if (EPI == EPI_SPLIT3_GELU || EPI == EPI_SPLIT2_GELU) {
       // strict fc1: GELU, the value split into its bf16 (hi, lo) pair, written as fc2's operand row [lo | hi | hi] per 32 columns
       // (ldo = 3 N) -- the arithmetic of tile256_epilogue's EPI_SPLIT3_GELU branch
 #if PG_STRICT_GELU_POLY
@@ -172,7 +172,7 @@ __device__ __forceinline__ void gemm_tail_tile64(const bf16_t* __restrict__ X, c
       bf16_t* o3 = (bf16_t*)out + (size_t)(m0 + m_loc) * ldo + (n >> 5) * 96 + (n & 31);
       *(uint2*)o3 = lo;
       *(uint2*)(o3 + 32) = hi;
-      *(uint2*)(o3 + 64) = hi;
+      if (EPI == EPI_SPLIT3_GELU) *(uint2*)(o3 + 64) = hi;
       continue;
     }
     const size_t o = (size_t)(m0 + m_loc) * ldo + n0 + n_loc;
@@ -238,12 +238,12 @@ __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int w
     }
     return;
   }
-  if (EPI == EPI_SPLIT3_GELU) {
+  if (EPI == EPI_SPLIT3_GELU || EPI == EPI_SPLIT2_GELU) {
     // Strict-mode fc1 (16-wave element order only): erf-GELU in registers, the value split into its bf16 (hi, lo) pair, and
     // the split operand rows of fc2 ([lo | hi | hi] per 32 columns, ldo = 3 N) written straight from here -- instead of an fp32 tile
     // plus a separate GELU-and-split pass over it (8 of 14 bytes per element less traffic).  Two halves of 128 token rows
     // (half h = tile rows with bit 5 == h = elements with bit 1 of e == h), each staged as a hi tile and a lo tile of 64 KB.
-    static_assert(EPI != EPI_SPLIT3_GELU || NW == 16, "element order of the 16-wave kernel");
+    static_assert((EPI != EPI_SPLIT3_GELU && EPI != EPI_SPLIT2_GELU) || NW == 16, "element order of the 16-wave kernel");
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (h) __syncthreads();
@@ -280,7 +280,7 @@ __device__ __forceinline__ void tile256_epilogue(ElemF&& elem, char* smem, int w
         bf16_t* o = (bf16_t*)out + (size_t)(m0 + (hr >> 5) * 64 + h * 32 + (hr & 31)) * ldo + ((n0 >> 5) + (c >> 2)) * 96 + (c & 3) * 8;
         PG_NT_STORE((uint4*)o, vl);
         PG_NT_STORE((uint4*)(o + 32), vh);
-        PG_NT_STORE((uint4*)(o + 64), vh);
+        if (EPI == EPI_SPLIT3_GELU) PG_NT_STORE((uint4*)(o + 64), vh);      // EPI_SPLIT2_GELU: the duplicate block stays unwritten
       }
     }
     return;

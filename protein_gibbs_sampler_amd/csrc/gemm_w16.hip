@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
   __shared__ __attribute__((aligned(16))) char smem[2 * W16_KSLOT];
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
   if ((int)blockIdx.x < n_tail) {
-    const int out_cols = EPI == EPI_SPLIT3_GELU ? ldo / 3 : ldo;
+    const int out_cols = (EPI == EPI_SPLIT3_GELU || EPI == EPI_SPLIT2_GELU) ? ldo / 3 : ldo;
     const int tn64 = tiles_n * 4, bt = blockIdx.x;
     (void)out_cols;
     gemm_tail_tile64<16, EPI, true>(X, W, bias, out, K, ldx, ldw, ldo, tail_m0 + (bt / tn64) * 64, (bt % tn64) * 64, smem);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_split3_w16_kernel(const bf16_t* 
 }
 
 // X3 [M][3K], W3 [N][3K] in the split operand layout; K = logical depth (a multiple of 32); M, N multiples of 256.
-// epi: EPI_F32, EPI_F32_RESID or EPI_SPLIT3_GELU.
+// epi: EPI_F32, EPI_F32_RESID, EPI_SPLIT3_GELU or EPI_SPLIT2_GELU.
 int launch_gemm_split3_w16(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const float* bias, void* out, int M, int N, int K,
                            int ldo, int epi) {
   if (M % 256 || N % 256 || K % 32 || K < 32 || M < 256) return fail(1, "gemm_split3_w16: shape");
@@ -300,6 +300,7 @@ int launch_gemm_split3_w16(hipStream_t s, const bf16_t* X3, const bf16_t* W3, co
     PG_S3_CASE(EPI_F32)
     PG_S3_CASE(EPI_F32_RESID)
     PG_S3_CASE(EPI_SPLIT3_GELU)
+    PG_S3_CASE(EPI_SPLIT2_GELU)
     default:
       return fail(1, "gemm_split3_w16: bad epilogue");
   }

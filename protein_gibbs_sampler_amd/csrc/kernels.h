@@ -40,7 +40,9 @@ using SeqLayout = ::PgSeqLayout;
 
 enum { EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_F32 = 3, EPI_F32_GELU = 4,
        EPI_F32_PARTIAL = 5 /* internal: split-K partial sums, no bias */,
-       EPI_SPLIT3_GELU = 6 /* strict mode fc1: erf-GELU, then the bf16 operand rows [lo | hi | hi] (ldo = 3 N) that fc2 reads; 16-wave kernel only */ };
+       EPI_SPLIT3_GELU = 6 /* strict mode fc1: erf-GELU, then the bf16 operand rows [lo | hi | hi] (ldo = 3 N) that fc2 reads; 16-wave kernel only */,
+       EPI_SPLIT2_GELU = 7 /* the same rows without the duplicate hi block ([lo | hi | --], same ldo): for an fc2 that runs on the fused
+                              three-product kernel, which never reads it (gemm_split3_fused) -- a third less epilogue traffic */ };
 
 // ---- the operand-flavoured kernel families (pg_common.h): declared in both namespaces, defined once per flavour ----
 inline namespace opbf16 {

@@ -48,7 +48,9 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[kMaxCh], int nch4, int la
 // row packed [hi | lo | hi] the same way, one bf16 GEMM over K' = 3 d sums, per 32 columns and in this order,
 // x_lo.w_hi + x_hi.w_lo + x_hi.w_hi in its fp32 accumulator -- whichever tile kernel runs it; the fused 16-wave kernel
 // (gemm_w16.hip) reads only the first two blocks of each group and issues the same three products from registers.
-__device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane, bool split3 = false) {
+// dup = false leaves the third block of every group unwritten (the consumer is the fused kernel: gemm_split3_fused).
+__device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kMaxCh], int nch4, int lane, bool split3 = false,
+                                               bool dup = true) {
 #pragma unroll
   for (int i = 0; i < kMaxCh; ++i)
     if (lane + 64 * i < nch4) {
@@ -65,7 +67,7 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* dst, const float4 (&v)[kM
         uint2* o = (uint2*)dst + (ci >> 3) * 24 + (ci & 7);      // group of 32 columns = 96 values = 24 uint2
         o[0] = q;
         o[8] = p;
-        o[16] = p;
+        if (dup) o[16] = p;
       }
     }
 }

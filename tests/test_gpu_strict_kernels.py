@@ -96,6 +96,49 @@ def test_fused_three_product_kernel_is_bit_identical_with_the_plain_gemm(tmp_pat
         assert (res["1"][k] == res["0"][k]).all(), k
 
 
+_NODUP_CHILD = """
+import sys, warnings
+import numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import models, weights
+rng = np.random.default_rng(5)
+outs = []
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    cfg = weights.make_config(weights.ESM1B_CONFIG, n_layers=2)
+    lm = models.ESM1b(state_dict=weights.synthetic_state_dict(cfg, seed=3), config=cfg, precision="fp32").model.to("cuda:0")
+    tok = np.concatenate([np.zeros((40, 1), np.int64), rng.integers(4, 24, (40, 256)), np.full((40, 1), 2)], axis=1)
+    tok[:, 7::11] = 32
+    outs.append(lm.forward_logits(tok))                      # 10 320 token rows: every projection on the fused kernel
+    outs.append(lm.forward_logits(tok[:3]))                  # 774 rows: the plain kernels, which read the duplicate block
+    cfg = weights.make_config(weights.MSA1B_CONFIG, n_layers=2)
+    lm = models.ESM_MSA1(state_dict=weights.synthetic_state_dict(cfg, seed=4), config=cfg, precision="fp32").model.to("cuda:0")
+    msa = np.concatenate([np.zeros((2, 64, 1), np.int64), rng.integers(4, 24, (2, 64, 256))], axis=2)
+    msa[:, 0, 5::9] = 32
+    outs.append(lm.forward_logits(msa))                      # 32 896 token rows
+    outs.append(lm.forward_logits(msa[:1, :4, :40]))
+np.savez(sys.argv[1], *[np.asarray(o) for o in outs])
+"""
+
+
+def test_skipping_the_duplicate_operand_block_changes_nothing(tmp_path):
+    """A producer of split operand rows (LayerNorm, fc1's epilogue) leaves the duplicate hi block of every 32-column group unwritten
+    when its consumer is the fused three-product kernel, which reads [lo | hi] only (Engine::dense3_wants_dup, EPI_SPLIT2_GELU);
+    PGIBBS_SPLIT3_NODUP=0 writes all three blocks as before.  Strict-mode logits of both engines, big (fused consumers) and small
+    (plain consumers, which do read the block -- after a big forward has left the buffers without it), must be equal bit for bit."""
+    res = {}
+    for nodup in ("1", "0"):
+        f = str(tmp_path / ("nodup%s.npz" % nodup))
+        env = dict(os.environ, PGIBBS_SPLIT3_NODUP=nodup)
+        p = subprocess.run([sys.executable, "-c", _NODUP_CHILD % ROOT, f], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        res[nodup] = np.load(f)
+    assert len(res["1"].files) == 4
+    for k in res["1"].files:
+        assert np.isfinite(res["1"][k]).all()
+        assert (res["1"][k] == res["0"][k]).all(), k
+
+
 def _attention_ref(qkv, d, H):
     B, T = qkv.shape[:2]
     r = qkv.astype(np.float64)
