@@ -68,6 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-mode leg (N = 1)")
+    ap.add_argument("--no-host-entry", action="store_true", help="skip the host-buffer entry-point leg (PCIe-inclusive rate; N = 1)")
     ap.add_argument("--no-msa", action="store_true", help="skip the ESM-MSA-1b legs (BASELINE configs 4 and 5; N = 1)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still create the torch.distributed process group (world_size 1) and run the final all-gather "
@@ -359,6 +360,24 @@ def main():
         assert random_ok, "gather changed the chain order"
         out["verified_vs_single_gpu"] = random_ok
 
+    # ---- N = 1: the same job through the HOST-buffer entry point (pg_esm_gibbs_run: tokens and position table cross PCIe inside
+    # the call, the tokens come back) -- the PCIe-inclusive rate; never `value`.  W + K iterations in one call from the initial
+    # tokens: the result must equal the device-pointer job's tokens bit for bit.
+    if not dry and dist is None and not args.no_host_entry and lo == 0 and hi == B_total:
+        r_h = pyrandom.NativePyRandom()
+        r_h.seed(0)
+        table_h = np.ascontiguousarray(sharding.global_position_table(r_h, population, P, W + K, B_total), dtype=np.int32)
+        tok_h = np.ascontiguousarray(tok_all.copy(), dtype=np.int32)
+        p_h = _lib.make_sample_params(True, cfg["mask_idx"], top_k, burnin, 1.0, valid_idx, rng_seed=0, rng_stream=0, row_id_base=0)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        lm.gibbs_run(tok_h, table_h, p_h)
+        th = time.perf_counter() - t0
+        out["host_buffer_entry"] = {"value": B_total * P * (W + K) / th, "unit": "sampled positions/s", "ms_per_step": 1e3 * th / (W + K),
+                                    "steps": W + K, "includes": "H2D of tokens + position table, D2H of tokens (PCIe), one native call",
+                                    "equals_device_pointer_job": bool((tok_h == final).all())}
+        assert out["host_buffer_entry"]["equals_device_pointer_job"], "host-buffer entry point disagrees with the device-pointer one"
+
     # ---- N > 1: the gathered tokens must equal the single-GPU result bit for bit (rank 0, outside the timed region) ----
     if not dry and dist is not None and not args.no_verify:
         if rank == 0:
@@ -517,6 +536,9 @@ def main():
             out["strict_mode"]["max_abs_logit_err"] = chk.get("fp32_max_abs_logit_err")
             out["strict_mode"]["logit_std"] = chk["logit_std"]
         out["bf16_max_abs_logit_err"] = chk.get("bf16_max_abs_logit_err")
+        # BASELINE config 1 (one chain, L = 25) measured on CPU and GPU inside cpu_baseline(): also at the top level of the line
+        if "config1" in out["cpu_baseline"]:
+            out["config1"] = out["cpu_baseline"]["config1"]
     # ---- N = 1: the ESM-MSA-1b configurations (BASELINE configs 4 and 5) on the same GPU, driver-timed -------------------
     if rank == 0 and world == 1 and not dry and not args.no_msa and args.precision == "bf16":
         import bench_msa
