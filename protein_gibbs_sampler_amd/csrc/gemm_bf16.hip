@@ -297,6 +297,58 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
   }
 }
 
+// out += tile for the 192 x 256 tile (XJ = 6): a wave holds token rows wm*96 + j*16 + fr, j < 6.  Two phases of 96 staged rows x
+// 1 KiB; in phase p every wave stages its columns j = 3p .. 3p+2 (48 token rows per wave group), then wave w owns the 12 staged
+// rows w*12 .. = token rows m0 + (w>>2)*96 + p*48 + (w&3)*12 + it.  x_old + (acc + bias) per element, as epilogue_256's residual
+// branch computes it; the same early row loads (phase 1's before phase 0's stores).
+__device__ __forceinline__ void epilogue_192_resid(f32x4 (&acc)[4][6], char* smem, int wm, int wn, int wave, int lane, int m0,
+                                                   int n0, const float* __restrict__ bias, void* __restrict__ out, int ldo) {
+  const int fr = lane & 15, fq = lane >> 4;
+  __syncthreads();
+  auto stage = [&](int p) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 b4 = *(const float4*)(bias + n0 + wn * 64 + i * 16 + fq * 4);
+      const int c = wn * 16 + i * 4 + fq;                         // 16-B chunk of the 1-KB row
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const int sr = wm * 48 + jj * 16 + fr;
+        const f32x4 a = acc[i][p * 3 + jj];
+        *(float4*)(smem + sr * 1024 + ((c ^ (sr & 63)) << 4)) = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+      }
+    }
+  };
+  auto grow = [&](int p) { return m0 + (wave >> 2) * 96 + p * 48 + (wave & 3) * 12; };
+  const rsrc_t rs0 = row_rsrc((float*)out + (size_t)grow(0) * ldo + n0);
+  const rsrc_t rs1 = row_rsrc((float*)out + (size_t)grow(1) * ldo + n0);
+  const int rstep = ldo * 4, voff = lane * 16;
+  f32x4 r0[12], r1[12];
+#pragma unroll
+  for (int it = 0; it < 12; ++it) r0[it] = buf_load_f32x4(rs0, voff, it * rstep);
+  __builtin_amdgcn_sched_barrier(0);
+  stage(0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int it = 0; it < 12; ++it) r1[it] = buf_load_f32x4(rs1, voff, it * rstep);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 12; ++it) {
+    const int sr = wave * 12 + it;
+    const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
+    buf_store_f32x4(r0[it] + v, rs0, voff, it * rstep);
+  }
+  __syncthreads();
+  stage(1);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 12; ++it) {
+    const int sr = wave * 12 + it;
+    const f32x4 v = *(const f32x4*)(smem + sr * 1024 + ((lane ^ (sr & 63)) << 4));
+    buf_store_f32x4(r1[it] + v, rs1, voff, it * rstep);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // "Ping-pong" 256x256x64 kernel (the hot one).
 //
@@ -318,7 +370,10 @@ __device__ __forceinline__ void epilogue_256(f32x4 (&acc)[4][8], char* smem, int
 // ------------------------------------------------------------------------------------------------
 // ABL (micro-benchmark ablations only): 0 = real kernel, 1 = no LDS-DMA inside the K loop (tile 0 reused),
 // 2 = no MFMA (fragments kept alive), 3 = no ds_read (fragments loaded once)
-template <int EPI, int ABL = 0, int GM = 4>
+// XJ = 16-row blocks of token rows per wave: 8 = the 256 x 256 tile; 6 = a 192 x 256 tile (residual epilogue only), chosen by
+// launch_gemm_big when 256-row tiles would leave a third of the CUs idle (165 tiles of a 32-chain shard's out-projection / fc2 on
+// 256 CUs: 220 tiles of three quarters the work instead).  Same k order per accumulator: a row's bits do not depend on the tile.
+template <int EPI, int ABL = 0, int GM = 4, int XJ = 8>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
                                                           int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
@@ -342,7 +397,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2;                      // 0: leads, 1: lags by one barrier
-  const int wm = grp, wn = wave & 3;              // wave tile: rows wm*128.. of X, rows wn*64.. of W
+  const int wm = grp, wn = wave & 3;              // wave tile: rows wm*(16 XJ).. of X, rows wn*64.. of W
+  static_assert(XJ == 8 || (XJ == 6 && EPI == EPI_F32_RESID && ABL == 0), "192-row tiles: residual epilogue only");
+  constexpr int TM = XJ * 32;                     // token rows per tile
+  constexpr int NPX = XJ / 2;                     // 16-row DMA pieces per X-staging wave and half-step (W-staging waves: 4)
 
   int bid = n_tail > 0 ? blockIdx.x - n_tail : blockIdx.x;
   if (ABL == 18 && (bid & 7) != 0) return;        // timing experiment: only the workgroups of XCD 0 run (1/8 of the tiles)
@@ -361,19 +419,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     tile_m = g * GM + within % rows;
     tile_n = within / rows;
   }
-  const int m0 = tile_m * 256;
+  const int m0 = tile_m * TM;
   const int n0 = tile_n * 256;
 
   // ---- LDS-DMA source addressing: wave stages pieces wave*4 .. wave*4+3 of the 32 pieces (16 rows each) of a
   // half-tile; pieces 0-15 are X rows, 16-31 are W rows.  lane -> row (lane>>2), LDS chunk (lane&3).
+  // (192-row tiles: the four X-staging waves take 3 pieces each, X rows 0..191 of the same LDS layout.)
   const bool stage_w = wave >= 4;
   const bf16_t* src = stage_w ? W : X;
   const int lds_ = stage_w ? ldw : ldx;
-  const int srow0 = (stage_w ? n0 : m0) + (wave & 3) * 64 + (lane >> 2);
+  const int srow0 = (stage_w ? n0 + (wave & 3) * 64 : m0 + (wave & 3) * (NPX * 16)) + (lane >> 2);
   const int schunk = (lane & 3) ^ ((0 - (lane >> 4)) & 3);                 // pi[(row>>2)&3] = (-g)&3
   const bf16_t* gsrc = src + (size_t)srow0 * lds_ + schunk * 8;            // + i*16 rows, + k
   const size_t piece_stride = (size_t)16 * lds_;
-  const int lds_piece0 = (stage_w ? 256 * 64 : 0) + (wave & 3) * 4 * 1024;  // byte offset inside a half-buffer
+  const int lds_piece0 = stage_w ? 256 * 64 + (wave & 3) * 4 * 1024 : (wave & 3) * NPX * 1024;  // byte offset inside a half-buffer
 
   auto stage_pieces = [&](int t, int kk, int i0, int i1) {
     char* hb = smem + ((t & 1) * 2 + kk) * HALF_BYTES + lds_piece0;
@@ -382,28 +441,36 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     for (int i = i0; i < i1; ++i)
       __builtin_amdgcn_global_load_lds(PG_GLB_PTR(g + i * piece_stride), PG_LDS_PTR(hb + i * 1024), 16, 0, 0);
   };
-  auto stage_half = [&](int t, int kk) { stage_pieces(t, kk, 0, 4); };
+  auto stage_half = [&](int t, int kk) {
+    if (XJ == 8 || stage_w) stage_pieces(t, kk, 0, 4); else stage_pieces(t, kk, 0, NPX);
+  };
+  // wait until at most `halves` of this wave's half-steps of DMA are still in flight (4 or NPX pieces each; wave-uniform branch)
+#define PG_PP_WAIT(halves, lgkm)                                                                              \
+  do {                                                                                                        \
+    if (XJ == 8 || stage_w) asm volatile("s_waitcnt vmcnt(%0)" lgkm ::"n"((halves) * 4) : "memory");          \
+    else asm volatile("s_waitcnt vmcnt(%0)" lgkm ::"n"((halves) * NPX) : "memory");                           \
+  } while (0)
 
-  f32x4 acc[4][8];
+  f32x4 acc[4][XJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < XJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / 64;                            // >= 2 (launcher)
   stage_half(0, 0);
   stage_half(0, 1);
   stage_half(1, 0);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // half-step 0 landed; 1 and 2 stay in flight
+  PG_PP_WAIT(2, "");                                // half-step 0 landed; 1 and 2 stay in flight
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();      // stagger the two groups by one barrier interval
 
   const int fr = lane & 15, fq = lane >> 4;
   const int foff = fr * 64 + ((fq ^ ((0 - (fr >> 2)) & 3)) << 4);          // row*64 + swizzled chunk*16
-  const int xoff = (wm * 128) * 64 + foff;
+  const int xoff = (wm * XJ * 16) * 64 + foff;
   const int woff = 256 * 64 + (wn * 64) * 64 + foff;
 
-  bf16x8 wf[4], xf[8];
+  bf16x8 wf[4], xf[XJ];
   for (int t = 0; t < (ABL == 13 ? 1 : nk); ++t) {          // ABL 13: one K-tile only -> times prologue + epilogue
     const bool has1 = (t + 1 < nk) && ABL != 13, has2 = (t + 2 < nk) && ABL != 13;
 #pragma unroll
@@ -420,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(hb + woff + i * 1024);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xf[j] = *(const bf16x8*)(hb + xoff + j * 1024);
+        for (int j = 0; j < XJ; ++j) xf[j] = *(const bf16x8*)(hb + xoff + j * 1024);
       }
       // half-step s+1 must have landed before the barrier; s+2 and s+3 (4 pieces each) may stay in flight
       if (NO_DMA) {
@@ -428,9 +495,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       } else if (ABL == 15) {                                         // timing only: never wait for the DMA
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if (issue) {
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        PG_PP_WAIT(2, " lgkmcnt(0)");
       } else if (kk == 1 && has1) {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // (t+1,0) needed, (t+1,1) in flight
+        PG_PP_WAIT(1, " lgkmcnt(0)");                                 // (t+1,0) needed, (t+1,1) in flight
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
@@ -443,13 +510,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
+          for (int j = 0; j < XJ; ++j)
             acc[i][j] = mfma_op16(wf[i], xf[j], acc[i][j]);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[i]));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(xf[j]));
+        for (int j = 0; j < XJ; ++j) asm volatile("" ::"v"(xf[j]));
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -458,15 +525,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();      // balance the barrier count
+#undef PG_PP_WAIT
 
   if (ABL == 10 || ABL == 11 || ABL == 12) {     // ablation: keep the accumulators alive, store nothing
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+      for (int j = 0; j < XJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
+  if constexpr (XJ == 8) epilogue_256<EPI, ABL == 16>(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
+  else epilogue_192_resid(acc, smem, wm, wn, wave, lane, m0, n0, bias, out, ldo);
 }
 
 // Measured alternatives that were NOT faster on MI355X and were removed again (QKV GEMM, M=66048 N=3840 K=1280, steady-state
@@ -492,8 +561,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 // without any epilogue at 1245-1273 TFLOP/s.
 // M rows of 256 x 256 tiles (M may be 0) + tail_rows rows of 64 x 64 tail tiles starting at row M, one grid
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0) {
-  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+                     int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0, int tile_rows = 256) {
+  const int tiles_m = M / tile_rows, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   static const int tail_last = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_LAST"); return e ? atoi(e) : 0; }();
   const int n_tail_abs = (tail_rows / 64) * (N / 64), tail_m0 = M;
   const int n_tail = tail_last ? -n_tail_abs : n_tail_abs;
@@ -528,6 +597,13 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
   // the W panels overflow the XCD's 4 MB L2 even slice-wise; measured 0.760 -> 0.733 ms with the bf16 epilogue)
   static const int gm_env = [] { const char* e = getenv("PGIBBS_GEMM_GM"); return e ? atoi(e) : 0; }();
   const int gm = gm_env ? gm_env : (K >= 4096 ? 2 : 4);
+  if (tile_rows == 192) {      // 192 x 256 tiles: residual epilogue only (launch_gemm_big)
+    if (epi != EPI_F32_RESID || M % 192) return fail(1, "gemm: 192-row tiles are for the residual epilogue");
+    if (gm == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 0, 2, 6>), grid, block, 0, s, PG_PP_ARGS);
+    else hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_F32_RESID, 0, 4, 6>), grid, block, 0, s, PG_PP_ARGS);
+    PG_HIP(hipGetLastError());
+    return 0;
+  }
 #define PG_GEMM_CASE(E)                                                                                                   \
   case E:                                                                                                                 \
     if (gm == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<E, 0, 1>), grid, block, 0, s, PG_PP_ARGS); \
@@ -585,6 +661,21 @@ int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
   const bool bf16out = epi == EPI_BF16 || epi == EPI_BF16_GELU;
   const bool use16 = big == 16 || (big == -1 && bf16out);
   if (use16) return launch_gemm_w16(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows);
+  // Residual GEMMs of mid-size batches: 256-row tiles quantise badly (a 32-chain shard's out-projection / fc2: 165 tiles on 256 CUs,
+  // a 64-chain one: 325 = two rounds of which the second is a quarter full).  192 x 256 tiles (same kernel, 6 instead of 8 row
+  // blocks per wave, same k order) cost three quarters of a round each: taken when that is at least 10 % fewer round-equivalents.
+  // The rows beyond the last 192-row tile (0, 64 or 128 of them: M is a multiple of 256) are 64 x 64 tail tiles of the same grid.
+  static const int t192 = [] { const char* e = getenv("PGIBBS_GEMM_T192"); return e ? atoi(e) : 1; }();
+  if (t192 && epi == EPI_F32_RESID) {
+    static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+    const int tiles_n = N / 256;
+    const long t256 = (long)(M / 256) * tiles_n;
+    const double r256 = tail_rows ? (double)((long)m_main * tiles_n / n_cu) + 0.15 : (double)((t256 + n_cu - 1) / n_cu);
+    const int m192 = M / 192, rest = M - m192 * 192;
+    const long t192n = (long)m192 * tiles_n;
+    const double r192 = 0.75 * (double)((t192n + n_cu - 1) / n_cu) + (rest ? 0.15 : 0.0);
+    if (t192 == 2 || r192 <= 0.9 * r256) return launch_pp(s, X, W, bias, out, m192 * 192, N, K, ldx, ldw, ldo, epi, 0, rest, 192);
+  }
   return launch_pp(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows);
 }
 

@@ -120,3 +120,39 @@ def test_attention(B, T, H):
     assert np.abs(ctx - ref).max() < 2.5e-2, np.abs(ctx - ref).max()
     assert np.abs(ctx - ref).mean() < 3e-3
 
+
+_T192_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import _lib
+outs = []
+for (M, N, K) in [(8448, 1280, 1280), (8448, 1280, 5120), (16640, 1280, 1280), (7168, 1280, 128), (7424, 1280, 320), (43008, 768, 768)]:
+    rng = np.random.default_rng(M + K)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
+    b = rng.standard_normal(N, dtype=np.float32)
+    out = rng.standard_normal((M, N), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_BF16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, 2))
+    outs.append(out[::7].copy())
+np.savez(sys.argv[1], *outs)
+"""
+
+
+def test_192_row_tiles_are_bit_identical_with_256_row_tiles(tmp_path):
+    """Residual GEMMs of mid-size batches run on 192 x 256 tiles when 256-row tiles would leave CUs idle (launch_gemm_big: a 32-chain
+    shard's out-projection has 165 tiles of 256 rows for 256 CUs).  PGIBBS_GEMM_T192=2 forces them for every big residual GEMM --
+    leftover rows of 0, 64 and 128 (64 x 64 tail tiles), both tile groupings, the shortest K -- =0 forbids them: equal bit for bit
+    (same k order per accumulator), which is what keeps a shard's logits identical with the whole batch's."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for sw in ("2", "0"):
+        f = str(tmp_path / ("t192_%s.npz" % sw))
+        p = subprocess.run([sys.executable, "-c", _T192_CHILD % root, f], capture_output=True, text=True,
+                           env=dict(os.environ, PGIBBS_GEMM_T192=sw), timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[sw] = np.load(f)
+    assert len(res["2"].files) == 6
+    for k in res["2"].files:
+        assert np.isfinite(res["2"][k]).all()
+        assert (res["2"][k] == res["0"][k]).all(), k
