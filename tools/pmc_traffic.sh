@@ -7,7 +7,7 @@
 TAG=${1:-r01}; ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/traf_${TAG}_$C -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-strict --no-fp16 --no-msa --layers 3 > /tmp/traf_run.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/traf_${TAG}_$C -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-strict --no-fp16 --no-msa --no-host-entry --layers 3 > /tmp/traf_run.log 2>&1
 done
 mkdir -p $ROOT/gpurun_out
 python - "$TAG" "$ROOT" <<'PY'

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r04ev; mkdir -p $O
 ( time python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json
-python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strict --no-fp16 --no-msa > $O/bench_50iters.json 2>> $O/bench_default.err
+python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strict --no-fp16 --no-msa --no-host-entry > $O/bench_50iters.json 2>> $O/bench_default.err
 bash tools/r03_prof.sh r04ev > $O/prof_cfg2.txt 2>&1; tail -16 $O/prof_cfg2.txt | cut -c1-170
 bash tools/r03_prof_msa.sh r04ev 4 > $O/prof_msa4.txt 2>&1; tail -16 $O/prof_msa4.txt | cut -c1-170
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profc1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc1 -o p -- python $GRAFT_REPO_ROOT/tools/cfg1_probe.py > /tmp/profc1.log 2>&1; cp $(find /tmp/profc1 -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/cfg1_kernel_stats.csv )
