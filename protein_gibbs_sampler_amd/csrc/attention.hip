@@ -43,28 +43,23 @@ __device__ unsigned long long* pg_att_prof;      // [workgroup][wave][8 slots][8
 
 // BIASKV: ESM-1's extra bias_k / bias_v key (a template parameter: the extra staging branch and the runtime key count cost the
 // config-2 kernel 8 % when they were runtime conditions)
-// PERSIST (plain keys only): two workgroups per CU walk the (sequence, head) pairs with a stride of the grid; the K / V rows of a
-// workgroup's NEXT pair are loaded into registers before the current pair's query blocks are computed and written to LDS after
-// them, so that a pair no longer starts with a cold HBM round trip that only the CU's other workgroup can hide.
-template <int MAXKB, bool PADMASK, bool BIASKV = false, bool PERSIST = false>
+template <int MAXKB, bool PADMASK, bool BIASKV = false>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                        SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx,
-                                                       const bf16_t* __restrict__ bias_kv, int n_pairs_) {
+                                                       const bf16_t* __restrict__ bias_kv) {
   __shared__ __attribute__((aligned(16))) char smem[2 * MAXKB * 16 * 128];
   char* Ks = smem;
   char* Vs = smem + MAXKB * 16 * 128;          // V rows, same layout as K: row*128 + ((chunk ^ (row & 7)) << 4)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   PG_T(7, 0);
-  static_assert(!PERSIST || (!PADMASK && !BIASKV), "persistent form: plain keys");
   // sequence `seq` = token rows row0 + t*row_step (ESM: contiguous rows of chain b; MSA column attention: the R rows
   // of one column, C token-rows apart)
+  const int seq = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t row0 = (size_t)(seq / sl.inner_count) * sl.outer_rows + (size_t)(seq % sl.inner_count) * sl.inner_rows;
   const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
-  auto pair_row0 = [&](int pair) {
-    const int seq = pair / H;
-    return (size_t)(seq / sl.inner_count) * sl.outer_rows + (size_t)(seq % sl.inner_count) * sl.inner_rows;
-  };
+  const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
   // ESM-1 (add_bias_kv): key T is the learned bias_k / bias_v of this head -- one more key, attended by every query, never masked
   const int Tk = T + (BIASKV ? 1 : 0);
   // All MAXKB key blocks are computed unconditionally: K rows / V^T columns past T are zero-filled and
@@ -74,11 +69,9 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 
   // ---- stage K and V (swizzled rows).  All global loads are issued before the first LDS write so a block pays
   //      ~one memory round trip, not one per loop iteration.
-  constexpr int NIT = (MAXKB * 16 * 8 + 255) / 256;       // one uint4 (8 d of one key) per item
-  uint4 kreg[NIT], vreg[NIT];
-  auto load_kv = [&](int pair) {
-    const int h = pair % H;
-    const bf16_t* base = qkv + pair_row0(pair) * ld_qkv_ + h * 64;
+  {
+    constexpr int NIT = (MAXKB * 16 * 8 + 255) / 256;       // one uint4 (8 d of one key) per item
+    uint4 kreg[NIT], vreg[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = tid + it * 256;
@@ -93,8 +86,6 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         vreg[it] = *(const uint4*)(bias_kv + (H + h) * 64 + c * 8);
       }
     }
-  };
-  auto store_kv = [&]() {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = tid + it * 256;
@@ -104,23 +95,13 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         *(uint4*)(Vs + row * 128 + ((c ^ (row & 7)) << 4)) = vreg[it];
       }
     }
-  };
-  int pair = blockIdx.x;
-  const int n_pairs = PERSIST ? n_pairs_ : (int)gridDim.x;
-  load_kv(pair);
-  store_kv();
+  }
   PG_T(7, 1);
   __syncthreads();
   PG_T(7, 2);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nqb = (T + 15) >> 4;  // query blocks of 16
-  for (;;) {
-  const int next = pair + (int)gridDim.x;
-  const bool has_next = PERSIST && next < n_pairs;
-  const int h = pair % H;
-  const size_t row0 = pair_row0(pair);
-  const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
   // Q fragment (MFMA B operand): query fr, d = kk*32 + fq*8 .. +7; the next block's fragment is prefetched while
   // the current one is computed (a wave has nothing else to cover a global round trip with)
   bf16x8 qf[2], qn[2];
@@ -131,7 +112,6 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
     for (int kk = 0; kk < 2; ++kk) dst[kk] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
   };
   if (wave < nqb) load_q(wave, qf);
-  if (has_next) load_kv(next);                   // behind the first Q fragment (loads return in order), in flight under this pair's query blocks
   for (int qb = wave; qb < nqb; qb += 4) {
     if (qb + 4 < nqb) load_q(qb + 4, qn);
     PG_T(qb >> 2, 0);
@@ -141,10 +121,7 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
     {
       // K fragments are fetched one chunk (CH key blocks) ahead of the MFMAs that use them: with 2 waves per SIMD
       // the LDS latency must be covered inside the wave (PMC: 44 % of wave cycles were s_waitcnt before this)
-#ifndef PG_ATT_PERSIST_CH
-#define PG_ATT_PERSIST_CH 3
-#endif
-      constexpr int CH = (PERSIST && MAXKB % PG_ATT_PERSIST_CH == 0) ? PG_ATT_PERSIST_CH : (MAXKB % 6 == 0) ? 6 : (MAXKB % 4 == 0 ? 4 : 2);
+      constexpr int CH = (MAXKB % 6 == 0) ? 6 : (MAXKB % 4 == 0 ? 4 : 2);
       bf16x8 kbuf[2][CH][2];
       auto load_chunk = [&](int ch, bf16x8 (&dst)[CH][2]) {
 #pragma unroll
@@ -294,12 +271,6 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
     qf[0] = qn[0];
     qf[1] = qn[1];
     PG_T(qb >> 2, 4);
-  }
-  if (!has_next) break;
-  __syncthreads();                               // every wave is done with this pair's K / V tile
-  store_kv();
-  __syncthreads();
-  pair = next;
   }
   PG_T(7, 3);
 }
@@ -474,16 +445,12 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   dim3 grid((unsigned)(n_seq * H)), block(256);
 #define PG_ATT(KB)                                                                                             \
   else if (Tk <= KB * 16) {                                                                                    \
-    if (bias_kv && key_tok) hipLaunchKernelGGL((attention_kernel<KB, true, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv, np); \
-    else if (bias_kv) hipLaunchKernelGGL((attention_kernel<KB, false, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv, np); \
-    else if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv, np); \
-    else if (persist && KB >= 12 && KB <= 18 && np > 2 * n_cu) hipLaunchKernelGGL((attention_kernel<(KB >= 12 && KB <= 18 ? KB : 18), false, false, true>), dim3(2 * n_cu), block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv, np); \
-    else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv, np); \
+    if (bias_kv && key_tok) hipLaunchKernelGGL((attention_kernel<KB, true, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else if (bias_kv) hipLaunchKernelGGL((attention_kernel<KB, false, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
   }
   const int Tk = T + (bias_kv ? 1 : 0);          // keys: the T tokens + ESM-1's bias_k / bias_v
-  static const int persist = [] { const char* e = getenv("PGIBBS_ATTN_PERSIST"); return e ? atoi(e) : 0; }();
-  static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-  const int np = (int)(n_seq * H);
   if (T <= 0) return fail(1, "attention: empty sequence");
   PG_ATT(2) PG_ATT(4) PG_ATT(8) PG_ATT(12) PG_ATT(18) PG_ATT(24) PG_ATT(30) PG_ATT(36)
 #undef PG_ATT
