@@ -25,6 +25,11 @@ batch, agreement of the shared sub-blocks (embedding, LayerNorm, FFN, LM head) w
 HF-corroborated ESM-1b oracle -- and against tests/_msa_alt.py, a second restatement written in
 fair-esm's own R x C x B x D layout with its einsum strings ("rinhd,rjnhd->hnij", "icnhd,jcnhd->hcnij")
 in torch, including fair-esm's chunked `max_tokens_per_msa` paths (chunked == unchunked).
+Since round 4 the two attention forms that only this model has are also checked against torch's own attention code, which shares
+nothing with this file: column attention against torch.nn.MultiheadAttention along the rows of every column (with and without a
+key-padding mask), tied row attention against torch.nn.functional.scaled_dot_product_attention over per-head feature vectors that
+concatenate the R rows (the tied map with q * dh^-0.5 / sqrt(R) IS scaled-dot-product attention of dimension R * dh).  What no
+independent code confirms is only the ASSEMBLY (the embedding sum with msa_position_embedding, the order row -> column -> FFN).
 """
 import numpy as np
 

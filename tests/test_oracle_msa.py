@@ -137,3 +137,73 @@ def test_padded_ragged_msa_batch_oracle_vs_fair_esm_layout_restatement():
     # MSA 2 padded in columns only (same rows): equals scoring it alone up to rounding -- pad columns are masked keys, masked column-attention rows
     alone2 = msa_forward(sd, ocfg, tok[2:3, :, :12])
     assert np.abs(alone2[0] - want[2, :, :12]).max() < 5e-5 * max(1.0, np.abs(want).max())
+
+
+# ---- the two attention forms that only the MSA Transformer has, against torch's own attention code ------------------------------
+# No MSA Transformer exists offline, but both of its attention blocks are ordinary attention in disguise, and torch's
+# implementations of ordinary attention share no code with the oracle:
+#   * column attention = multi-head attention along the R rows of every column -> torch.nn.MultiheadAttention (with a key-padding
+#     mask for the <pad> case; fair-esm's finite -10000 fill and torch's -inf agree wherever a column has a real key);
+#   * TIED row attention: scores summed over the rows with q scaled by dh^-0.5 / sqrt(R) = scaled-dot-product attention over the
+#     C columns whose per-head feature vector is the concatenation of the R rows' features (dimension R * dh, default scale
+#     1 / sqrt(R * dh)) -> torch.nn.functional.scaled_dot_product_attention.
+def _proj_weights(p):
+    import torch
+    return {k: torch.from_numpy(W[p + k]) for k in ("q_proj.weight", "q_proj.bias", "k_proj.weight", "k_proj.bias", "v_proj.weight",
+                                                    "v_proj.bias", "out_proj.weight", "out_proj.bias")}
+
+
+def test_column_attention_against_torch_multihead_attention():
+    import torch
+    p = "layers.1.column_self_attention.layer."
+    B, R, C, d, H = 2, 6, 5, CFG.d_model, CFG.n_heads
+    h = RNG.standard_normal((B, R, C, d)).astype(np.float32)
+    pw = _proj_weights(p)
+    m = torch.nn.MultiheadAttention(d, H, bias=True, batch_first=True)
+    with torch.no_grad():
+        m.in_proj_weight.copy_(torch.cat([pw["q_proj.weight"], pw["k_proj.weight"], pw["v_proj.weight"]]))
+        m.in_proj_bias.copy_(torch.cat([pw["q_proj.bias"], pw["k_proj.bias"], pw["v_proj.bias"]]))
+        m.out_proj.weight.copy_(pw["out_proj.weight"])
+        m.out_proj.bias.copy_(pw["out_proj.bias"])
+        x = torch.from_numpy(h).permute(0, 2, 1, 3).reshape(B * C, R, d)          # one sequence of R rows per (msa, column)
+        want = m(x, x, x, need_weights=False)[0].reshape(B, C, R, d).permute(0, 2, 1, 3).numpy()
+        got = column_attention(W, p, CFG, h)
+        assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
+        # <pad> keys (ragged MSA lists): rows 4, 5 of MSA 1 are padding in every column
+        pad = np.zeros((B, R, C), bool)
+        pad[1, 4:] = True
+        kpm = torch.from_numpy(pad).permute(0, 2, 1).reshape(B * C, R)
+        want = m(x, x, x, key_padding_mask=kpm, need_weights=False)[0].reshape(B, C, R, d).permute(0, 2, 1, 3).numpy()
+        got = column_attention(W, p, CFG, h, pad)
+        real = ~pad                                                               # outputs AT padded positions are never used
+        assert np.abs(got - want)[real].max() < 3e-5 * max(1.0, np.abs(want).max())
+
+
+def test_tied_row_attention_against_torch_scaled_dot_product_attention():
+    import torch
+    import torch.nn.functional as F
+    p = "layers.0.row_self_attention.layer."
+    B, R, C, d, H = 2, 5, 9, CFG.d_model, CFG.n_heads
+    dh = d // H
+    h = RNG.standard_normal((B, R, C, d)).astype(np.float32)
+    pw = _proj_weights(p)
+    with torch.no_grad():
+        x = torch.from_numpy(h)
+        q, k, v = (F.linear(x, pw[n + "_proj.weight"], pw[n + "_proj.bias"]).reshape(B, R, C, H, dh) for n in "qkv")
+        # per head: C "tokens" with R * dh features each (the rows concatenated); default scale = (R * dh)^-0.5
+        cat = lambda t: t.permute(0, 3, 2, 1, 4).reshape(B, H, C, R * dh)          # noqa: E731
+        ctx = F.scaled_dot_product_attention(cat(q), cat(k), cat(v))              # [B, H, C, R * dh]
+        ctx = ctx.reshape(B, H, C, R, dh).permute(0, 3, 2, 1, 4).reshape(B, R, C, d)
+        want = F.linear(ctx, pw["out_proj.weight"], pw["out_proj.bias"]).numpy()
+    got = row_attention(W, p, CFG, h)
+    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
+    # one row: plain attention along the columns, i.e. torch.nn.MultiheadAttention once more
+    m = torch.nn.MultiheadAttention(d, H, bias=True, batch_first=True)
+    with torch.no_grad():
+        m.in_proj_weight.copy_(torch.cat([pw["q_proj.weight"], pw["k_proj.weight"], pw["v_proj.weight"]]))
+        m.in_proj_bias.copy_(torch.cat([pw["q_proj.bias"], pw["k_proj.bias"], pw["v_proj.bias"]]))
+        m.out_proj.weight.copy_(pw["out_proj.weight"])
+        m.out_proj.bias.copy_(pw["out_proj.bias"])
+        x1 = torch.from_numpy(h[:, :1]).reshape(B, C, d)
+        want1 = m(x1, x1, x1, need_weights=False)[0].reshape(B, 1, C, d).numpy()
+    assert np.abs(row_attention(W, p, CFG, h[:, :1]) - want1).max() < 3e-5 * max(1.0, np.abs(want1).max())
