@@ -281,11 +281,19 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 // One workgroup = (sequence, head, 64 queries); wave w owns one 16-query block for the whole key loop, so the
 // per-wave state is just O (16 regs) + m + l; every workgroup streams all K/V tiles of its head (L2-resident).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attention_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
+// MAXKB = 16-key blocks per tile (even), OCC = workgroups per CU the register / LDS budget is set for: <18, 2> is the long-sequence
+// kernel.  <10, 4> (160-key tiles, four workgroups per CU, 117 VGPRs) and <12, 3> were measured at config 2 in round 4 against
+// attention_kernel: 9.1 / 11.1 ms per iteration against 7.0 (EXPERIMENTS.md) -- every 64-query workgroup re-stages the head's K / V.
+template <int MAXKB, int OCC, bool PADMASK, bool BIASKV>
+__global__ __launch_bounds__(256, OCC) void attention_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                                int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
-                                                               SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok,
-                                                               int pad_idx, const bf16_t* __restrict__ bias_kv) {
-  constexpr int MAXKB = 18, tpad = MAXKB * 16, nkc = MAXKB / 2;
+                                                               SeqLayout sl, int n_qchunk, const int32_t* __restrict__ key_tok_,
+                                                               int pad_idx, const bf16_t* __restrict__ bias_kv_) {
+  // the <pad> mask and ESM-1's bias key as template parameters (as in attention_kernel): as runtime conditions they kept the kernel
+  // at 256 VGPRs with 110 dwords of scratch
+  const int32_t* __restrict__ key_tok = PADMASK ? key_tok_ : nullptr;
+  const bf16_t* __restrict__ bias_kv = BIASKV ? bias_kv_ : nullptr;
+  constexpr int tpad = MAXKB * 16, nkc = MAXKB / 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128];
   char* Ks = smem;
   char* Vs = smem + tpad * 128;
@@ -457,8 +465,13 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   else {
     const int n_qchunk = (T + 63) / 64;
     if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");
-    hipLaunchKernelGGL(attention_long_kernel, dim3((unsigned)(n_seq * H * n_qchunk)), block, 0, s, qkv, ctx, T, H, ld_qkv,
-                       ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx, bias_kv);
+    const dim3 g((unsigned)(n_seq * H * n_qchunk));
+#define PG_ATT_LONG(P, B) hipLaunchKernelGGL((attention_long_kernel<18, 2, P, B>), g, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx, bias_kv)
+    if (key_tok && bias_kv) PG_ATT_LONG(true, true);
+    else if (key_tok) PG_ATT_LONG(true, false);
+    else if (bias_kv) PG_ATT_LONG(false, true);
+    else PG_ATT_LONG(false, false);
+#undef PG_ATT_LONG
   }
   PG_HIP(hipGetLastError());
   return 0;
