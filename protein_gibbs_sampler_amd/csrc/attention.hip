@@ -48,9 +48,10 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                        SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx,
                                                        const bf16_t* __restrict__ bias_kv) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * MAXKB * 16 * 128];
+  __shared__ __attribute__((aligned(16))) char smem[2 * MAXKB * 16 * 128 + (PADMASK ? MAXKB * 16 : 0)];
   char* Ks = smem;
   char* Vs = smem + MAXKB * 16 * 128;          // V rows, same layout as K: row*128 + ((chunk ^ (row & 7)) << 4)
+  char* padf = smem + 2 * MAXKB * 16 * 128;    // PADMASK: one byte per key, 1 = this key's token is <pad>
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   PG_T(7, 0);
@@ -95,6 +96,12 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
         *(uint4*)(Vs + row * 128 + ((c ^ (row & 7)) << 4)) = vreg[it];
       }
     }
+  }
+  if (PADMASK) {
+    // the <pad> flags of the sequence's keys, once per workgroup (read per key inside the score loop they were 72 dependent global
+    // loads per lane and query block: 292 bytes of scratch, a ragged batch's attention 5x the time of a full one)
+    for (int key = tid; key < MAXKB * 16; key += 256)
+      padf[key] = (key < T && key_tok[row0 + (size_t)key * sl.row_step] == pad_idx) ? 1 : 0;
   }
   PG_T(7, 1);
   __syncthreads();
@@ -175,16 +182,14 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
       // of the MSA Transformer's column attention get its finite fill of -10000 (an all-<pad> column then softmaxes to a uniform
       // row instead of NaN, exactly as fair-esm's ColumnSelfAttention does -- and NaN at a padded position would reach the real
       // ones through 0 * NaN in the next tied row attention).
-      const int32_t* kt = key_tok + row0;
-      const int kstep = sl.row_step;
-      const float fill = kstep == 1 ? -3.0e38f : -10000.0f;
+      const float fill = sl.row_step == 1 ? -3.0e38f : -10000.0f;
       mx = -3.0e38f;
 #pragma unroll
       for (int kb = 0; kb < MAXKB; ++kb) {
+        const uint32_t f4 = *(const uint32_t*)(padf + kb * 16 + fq * 4);     // keys kb*16 + fq*4 .. +3
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kb * 16 + fq * 4 + r;
-          if (key < T && kt[(size_t)key * kstep] == pad_idx) st[kb][r] = fill;
+          if ((f4 >> (8 * r)) & 0xffu) st[kb][r] = fill;
           mx = fmaxf(mx, st[kb][r]);
         }
       }
@@ -294,9 +299,10 @@ __global__ __launch_bounds__(256, OCC) void attention_long_kernel(const bf16_t* 
   const int32_t* __restrict__ key_tok = PADMASK ? key_tok_ : nullptr;
   const bf16_t* __restrict__ bias_kv = BIASKV ? bias_kv_ : nullptr;
   constexpr int tpad = MAXKB * 16, nkc = MAXKB / 2;
-  __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128];
+  __shared__ __attribute__((aligned(16))) char smem[2 * tpad * 128 + (PADMASK ? tpad : 0)];
   char* Ks = smem;
   char* Vs = smem + tpad * 128;
+  char* padf = smem + 2 * tpad * 128;             // PADMASK: one byte per key of the tile, 1 = <pad> token (see attention_kernel)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qc = blockIdx.x % n_qchunk, sh = blockIdx.x / n_qchunk;
   const int seq = sh / H, h = sh % H;
@@ -347,6 +353,10 @@ __global__ __launch_bounds__(256, OCC) void attention_long_kernel(const bf16_t* 
         }
       }
     }
+    if (PADMASK) {
+      for (int key = tid; key < tpad; key += 256)
+        padf[key] = (k0 + key < T && key_tok[row0 + (size_t)(k0 + key) * sl.row_step] == pad_idx) ? 1 : 0;
+    }
     __syncthreads();
     if (!active) continue;
     f32x4 st[MAXKB];
@@ -369,18 +379,18 @@ __global__ __launch_bounds__(256, OCC) void attention_long_kernel(const bf16_t* 
         if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
         tmax = fmaxf(tmax, st[kb][r]);
       }
-    if (key_tok) {                               // <pad> keys of a ragged batch (see attention_kernel)
-      const int32_t* kt = key_tok + row0 + (size_t)k0 * sl.row_step;
+    if (PADMASK) {                               // <pad> keys of a ragged batch (see attention_kernel)
       const float fill = sl.row_step == 1 ? -3.0e38f : -10000.0f;
       tmax = -3.0e38f;
 #pragma unroll
-      for (int kb = 0; kb < MAXKB; ++kb)
+      for (int kb = 0; kb < MAXKB; ++kb) {
+        const uint32_t f4 = *(const uint32_t*)(padf + kb * 16 + fq * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kb * 16 + fq * 4 + r;
-          if (k0 + key < T && kt[(size_t)key * sl.row_step] == pad_idx) st[kb][r] = fill;
+          if ((f4 >> (8 * r)) & 0xffu) st[kb][r] = fill;
           tmax = fmaxf(tmax, st[kb][r]);
         }
+      }
     }
     tmax = rows4_max(tmax);
     const float mn = fmaxf(m, tmax);
