@@ -126,13 +126,15 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 from protein_gibbs_sampler_amd import _lib
 outs = []
-for (M, N, K) in [(8448, 1280, 1280), (8448, 1280, 5120), (16640, 1280, 1280), (7168, 1280, 128), (7424, 1280, 320), (43008, 768, 768)]:
+for (M, N, K, prec) in [(8448, 1280, 1280, _lib.PG_PREC_BF16), (8448, 1280, 5120, _lib.PG_PREC_BF16), (16640, 1280, 1280, _lib.PG_PREC_BF16),
+                        (7168, 1280, 128, _lib.PG_PREC_BF16), (7424, 1280, 320, _lib.PG_PREC_BF16), (43008, 768, 768, _lib.PG_PREC_BF16),
+                        (8448, 1280, 1280, _lib.PG_PREC_F16), (7168, 1280, 5120, _lib.PG_PREC_F16)]:      # the fp16-operand flavour too
     rng = np.random.default_rng(M + K)
     x = rng.standard_normal((M, K), dtype=np.float32)
     w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
     b = rng.standard_normal(N, dtype=np.float32)
     out = rng.standard_normal((M, N), dtype=np.float32)
-    _lib.check(_lib.lib().pg_dbg_gemm(0, _lib.PG_PREC_BF16, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, 2))
+    _lib.check(_lib.lib().pg_dbg_gemm(0, prec, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, 2))
     outs.append(out[::7].copy())
 np.savez(sys.argv[1], *outs)
 """
@@ -152,7 +154,7 @@ def test_192_row_tiles_are_bit_identical_with_256_row_tiles(tmp_path):
                            env=dict(os.environ, PGIBBS_GEMM_T192=sw), timeout=900)
         assert p.returncode == 0, p.stderr[-3000:]
         res[sw] = np.load(f)
-    assert len(res["2"].files) == 6
+    assert len(res["2"].files) == 8
     for k in res["2"].files:
         assert np.isfinite(res["2"][k]).all()
         assert (res["2"][k] == res["0"][k]).all(), k
