@@ -11,3 +11,8 @@ bash tools/r03_prof_msa.sh r04ev 4 > $O/prof_msa4.txt 2>&1; tail -16 $O/prof_msa
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profc1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profc1 -o p -- python $GRAFT_REPO_ROOT/tools/cfg1_probe.py > /tmp/profc1.log 2>&1; cp $(find /tmp/profc1 -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/cfg1_kernel_stats.csv )
 bash tools/pmc_traffic.sh r04 > $O/traffic.txt 2>&1; tail -14 $O/traffic.txt | cut -c1-170
 python tools/shard_regime.py --engine > $O/shard_regime.txt 2>&1; tail -8 $O/shard_regime.txt
+# fabric traffic of the MSA kernels, PMC counters of the hot kernels (matrix-pipe utilisation, L2 hit rate), strict-mode kernel stats
+bash tools/pmc_traffic_msa.sh r04 > $O/traffic_msa.txt 2>&1; tail -8 $O/traffic_msa.txt | cut -c1-150
+for k in gemm_bf16_w16_kernel gemm_bf16_pp_kernel attention_kernel; do echo "== $k"; bash tools/pmc_bench.sh $k r04$k; done 2>&1 | grep -E "^==|^pass" > $O/gemm_pmc_counters.txt
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_strict && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_strict -o p -- python $GRAFT_REPO_ROOT/bench.py --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-msa --no-fp16 --no-roofline --no-host-entry > /tmp/prof_strict.log 2>&1; cp $(find /tmp/prof_strict -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$O/strict_cfg2_kernel_stats.csv )
+SOAK_ITERS=200 SOAK_REPS=3 python tools/soak_test.py > $O/soak.txt 2>&1; tail -3 $O/soak.txt
