@@ -41,9 +41,28 @@ def layer_norm(x, w, b, eps=1e-5):
     return (xc / np.sqrt(var + F32(eps)) * w + b).astype(F32)
 
 
-def gelu(x):
-    x = x.astype(F32)
+def _gelu_block(x):
     return (F32(0.5) * x * (F32(1.0) + erf(x * F32(0.7071067811865476)))).astype(F32)
+
+
+def gelu(x):
+    """exact (erf) GELU, elementwise; big arrays in row blocks on a thread pool (scipy's erf is a single-threaded ufunc that releases
+    the GIL: 30 % of a full-size forward otherwise) -- the same value per element either way."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    if x.size < (1 << 22) or x.ndim < 2:
+        return _gelu_block(x)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    flat = x.reshape(-1, x.shape[-1])
+    n = min(os.cpu_count() or 1, 64, flat.shape[0])
+    out = np.empty_like(flat)
+    bounds = np.linspace(0, flat.shape[0], n + 1).astype(int)
+
+    def run(i):
+        out[bounds[i]:bounds[i + 1]] = _gelu_block(flat[bounds[i]:bounds[i + 1]])
+    with ThreadPoolExecutor(n) as ex:
+        list(ex.map(run, range(n)))
+    return out.reshape(x.shape)
 
 
 def linear(x, w, b):

@@ -73,11 +73,17 @@ def row_attention(w, p, cfg, h, pad=None):
     v = linear(h, w[p + "v_proj.weight"], w[p + "v_proj.bias"]).reshape(B, R, C, H, dh)
     if pad is not None:
         q = np.where(pad[..., None, None], F32(0), q)
-    a = np.einsum("brihd,brjhd->bhij", q, k, optimize=True).astype(F32)
+    # A[b,h,i,j] = sum_{r,d} q[b,r,i,h,d] k[b,r,j,h,d] as one matrix product per (b, h) over the R * dh concatenated features, and
+    # ctx[b,r,i,h,:] = sum_j P[b,h,i,j] v[b,r,j,h,:] likewise ("brihd,brjhd->bhij" / "bhij,brjhd->brihd": numpy's einsum walks these
+    # in single-threaded C loops, 40 % of a 128 x 513 alignment's 400 s; the BLAS products are the same sums in another order)
+    qc = np.ascontiguousarray(q.transpose(0, 3, 2, 1, 4)).reshape(B, H, C, R * dh)
+    kc = np.ascontiguousarray(k.transpose(0, 3, 2, 1, 4)).reshape(B, H, C, R * dh)
+    a = np.matmul(qc, kc.transpose(0, 1, 3, 2)).astype(F32)                        # [B, H, C(i), C(j)]
     if pad is not None:
         a = np.where(pad[:, 0][:, None, None, :], F32(-10000.0), a)
     pr = softmax_lastdim(a)
-    ctx = np.einsum("bhij,brjhd->brihd", pr, v, optimize=True).astype(F32).reshape(B, R, C, d)
+    vc = np.ascontiguousarray(v.transpose(0, 3, 2, 1, 4)).reshape(B, H, C, R * dh)  # [B, H, C(j), R * dh]
+    ctx = np.matmul(pr, vc).astype(F32).reshape(B, H, C, R, dh).transpose(0, 3, 2, 1, 4).reshape(B, R, C, d)
     return linear(ctx, w[p + "out_proj.weight"], w[p + "out_proj.bias"])
 
 
@@ -91,11 +97,15 @@ def column_attention(w, p, cfg, h, pad=None):
     q = linear(h, w[p + "q_proj.weight"], w[p + "q_proj.bias"]).reshape(B, R, C, H, dh) * F32(dh ** -0.5)
     k = linear(h, w[p + "k_proj.weight"], w[p + "k_proj.bias"]).reshape(B, R, C, H, dh)
     v = linear(h, w[p + "v_proj.weight"], w[p + "v_proj.bias"]).reshape(B, R, C, H, dh)
-    a = np.einsum("bichd,bjchd->bhcij", q, k, optimize=True).astype(F32)
+    # per (b, h, column c): attention along the rows ("bichd,bjchd->bhcij" / "bhcij,bjchd->bichd" as batched matrix products)
+    qc = q.transpose(0, 3, 2, 1, 4)                                                  # [B, H, C, R(i), dh]
+    kc = k.transpose(0, 3, 2, 4, 1)                                                  # [B, H, C, dh, R(j)]
+    a = np.matmul(qc, kc).astype(F32)                                                # [B, H, C, R(i), R(j)]
     if pad is not None:
         a = np.where(pad.transpose(0, 2, 1)[:, None, :, None, :], F32(-10000.0), a)      # [B,1,C,1,R(j)]
     pr = softmax_lastdim(a)
-    ctx = np.einsum("bhcij,bjchd->bichd", pr, v, optimize=True).astype(F32).reshape(B, R, C, d)
+    ctx = np.matmul(pr, v.transpose(0, 3, 2, 1, 4)).astype(F32)                      # [B, H, C, R(i), dh]
+    ctx = ctx.transpose(0, 3, 2, 1, 4).reshape(B, R, C, d)
     return linear(ctx, w[p + "out_proj.weight"], w[p + "out_proj.bias"])
 
 
