@@ -264,10 +264,20 @@ static void row_split_geometry(int n_bh, int obh, int R, int C, int& nw, int& n_
     if (n_rc > R / 4) n_rc = R / 4;
     if (n_rc < 1) n_rc = 1;
   }
-  static const int kbs[] = {2, 4, 8, 12, 18, 24, 30, 36};
+  // a rung for every even block count (round 4; PGIBBS_ATTN_LADDER=0: the coarse ladder 2 4 8 12 18 24 30 36): the key blocks beyond C
+  // are zero-filled and masked -- exact zeros in every sum, so the rung does not change the bits, only the wasted work
+  static const int fine = [] { const char* e = getenv("PGIBBS_ATTN_LADDER"); return e ? atoi(e) : 1; }();
+  static const int kbs_fine[] = {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36};
+  static const int kbs_coarse[] = {2, 4, 8, 12, 18, 24, 30, 36};
+  const int* kbs = fine ? kbs_fine : kbs_coarse;
+  const int n_kbs = fine ? 18 : 8;
   kb = 36;
-  for (int k : kbs)
-    if (C <= k * 16) { kb = k; break; }
+  for (int i = 0; i < n_kbs; ++i)
+    if (C <= kbs[i] * 16) { kb = kbs[i]; break; }
+  // One exception, measured (profiles/r04_attention_key_block_ladder_ab.txt): the 20-block rung needs 80 KB of LDS, so TWO of its
+  // workgroups fit a CU where one of the 24-block rung does -- and the dispatcher packs a grid smaller than two rounds onto half of the
+  // CUs (one template of 32 x 301: 288 workgroups, 0.97 ms against 0.88).  Such grids stay on the 24-block rung.
+  if (kb == 20 && (long)n_bh * n_qblk * n_rc < 512) kb = 24;
   (void)n_bh;
 }
 // bytes of fp32 scratch the split-R form needs for B alignments (0: the shape does not split)
@@ -284,6 +294,7 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
                                   int order_bh) {
   if (B == 0 || R == 0) return 0;
   if (C <= 0) return fail(1, "row attention: empty alignment");
+  if (C > 576) return fail(5, "row attention: alignments wider than 575 columns take the fp32-scores path");
   const int n_bh = B * H;
   // workgroup width: 4 waves up to 64 columns, beyond that the widest the register budget of the score fragments allows
   // (9 waves up to 288 keys, 8 beyond).  The row loop is split over workgroups when the (msa, head, query-chunk) grid alone
@@ -296,7 +307,7 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
   hipLaunchKernelGGL((msa_row_attention_kernel<KB, NWV, MODE>), GRID, BLOCK, 0, s, qkv, ctx, R, C, H, ld_qkv, ld_ctx,     \
                      k_off, v_off, scale, n_qblk, n_bh, n_rc, partial)
 #define PG_ROWATT(KB, NWV)                                                                                              \
-  else if (C <= KB * 16) {                                                                                              \
+  else if (kb_ == KB) {                                                                                                 \
     if (n_rc > 1 && (size_t)n_bh * n_rc * C * (KB * 16) * 4 + (size_t)n_bh * n_qblk * nw * (KB / 2) * 1024 > partial_bytes) n_rc = 1; \
     const dim3 block(NWV * 64), grid((unsigned)(n_bh * n_qblk * n_rc));                                                 \
     if (n_rc == 1) {                                                                                                    \
@@ -308,7 +319,9 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
     }                                                                                                                   \
   }
   if (false) {}
-  PG_ROWATT(2, 4) PG_ROWATT(4, 4) PG_ROWATT(8, 9) PG_ROWATT(12, 9) PG_ROWATT(18, 9) PG_ROWATT(24, 8) PG_ROWATT(30, 8) PG_ROWATT(36, 8)
+  PG_ROWATT(2, 4) PG_ROWATT(4, 4) PG_ROWATT(6, 9) PG_ROWATT(8, 9) PG_ROWATT(10, 9) PG_ROWATT(12, 9) PG_ROWATT(14, 9) PG_ROWATT(16, 9)
+  PG_ROWATT(18, 9) PG_ROWATT(20, 8) PG_ROWATT(22, 8) PG_ROWATT(24, 8) PG_ROWATT(26, 8) PG_ROWATT(28, 8) PG_ROWATT(30, 8) PG_ROWATT(32, 8)
+  PG_ROWATT(34, 8) PG_ROWATT(36, 8)
 #undef PG_ROWATT
 #undef PG_ROWATT_K
   else {
