@@ -274,9 +274,9 @@ static void row_split_geometry(int n_bh, int obh, int R, int C, int& nw, int& n_
   kb = 36;
   for (int i = 0; i < n_kbs; ++i)
     if (C <= kbs[i] * 16) { kb = kbs[i]; break; }
-  // One exception, measured (profiles/r04_attention_key_block_ladder_ab.txt): the 20-block rung needs 80 KB of LDS, so TWO of its
-  // workgroups fit a CU where one of the 24-block rung does -- and the dispatcher packs a grid smaller than two rounds onto half of the
-  // CUs (one template of 32 x 301: 288 workgroups, 0.97 ms against 0.88).  Such grids stay on the 24-block rung.
+  // One exception, measured (profiles/r04_attention_key_block_ladder_ab.txt): one template of 32 x 301 (288 workgroups, split-R form)
+  // takes 0.97 ms on the 20-block rung against 0.88 on the 24-block one, while bigger grids gain 10 %.  (The 20-block rung's 80 KB of
+  // LDS lets two workgroups share a CU; whether that is the cause was not established.)  Grids below two rounds stay on 24 blocks.
   if (kb == 20 && (long)n_bh * n_qblk * n_rc < 512) kb = 24;
   (void)n_bh;
 }
