@@ -613,6 +613,7 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
   // 16-query blocks per wave of the split kernel (its workgroup = 64 * nqb queries, all of them against each staged K / V tile):
   // the smallest of 1, 2, 3, 5 that covers the sequence with one workgroup, else 5 (PGIBBS_ATTN_F32_NQB overrides: A/B runs)
   static const int nqb_env = [] { const char* e = getenv("PGIBBS_ATTN_F32_NQB"); return e ? atoi(e) : 0; }();
+  static const int kb_env = [] { const char* e = getenv("PGIBBS_ATTN_F32_KB"); return e ? atoi(e) : 0; }();   // experiment: key-tile height
   const int blocks = (T + 15) / 16;
   int nqb = blocks <= 4 ? 1 : (blocks <= 8 ? 2 : (blocks <= 12 ? 3 : 5));
   if (nqb_env == 1 || nqb_env == 2 || nqb_env == 3 || nqb_env == 5) nqb = nqb_env;
@@ -626,6 +627,19 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
   } else {
     // key tile: 64 keys for short sequences, else 160 (80 KB of LDS: two workgroups per CU; at T = 258 a single 288-key
     // tile with one workgroup per CU was 1.6x slower)
+    // Long plain sequences (five query blocks per wave): the tile height of 6, 8 or 10 key blocks that pads the keys least -- the
+    // kernel's time follows the padded key count (T = 258: 3 x 96 = 288 keys 18.8 ms per config-2 iteration, 2 x 160 = 320 keys
+    // 20.5, 3 x 128 = 384 keys 25.7); ties go to the taller tile.  PGIBBS_ATTN_F32_KB = 6 / 8 / 10 forces one.
+    int kb5 = 10;
+    {
+      const int Tk = T;                                // plain form only (no bias key)
+      long best = ((long)Tk + 159) / 160 * 160;
+      for (int k : {8, 6}) {
+        const long padded = ((long)Tk + 16 * k - 1) / (16 * k) * (16 * k);
+        if (padded < best) { best = padded; kb5 = k; }
+      }
+      if (kb_env == 6 || kb_env == 8 || kb_env == 10) kb5 = kb_env;
+    }
 #define PG_ATT_SPLIT(KB, NQ)                                                                                                  \
   do {                                                                                                                        \
     if (bias_kv && key_tok) hipLaunchKernelGGL((attention_split_kernel<KB, NQ, true, true>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, \
@@ -641,6 +655,8 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
     else if (nqb == 1) PG_ATT_SPLIT(10, 1);
     else if (nqb == 2) PG_ATT_SPLIT(10, 2);
     else if (nqb == 3) PG_ATT_SPLIT(10, 3);
+    else if (kb5 == 6 && !bias_kv && !key_tok) hipLaunchKernelGGL((attention_split_kernel<6, 5, false, false>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx, bias_kv);
+    else if (kb5 == 8 && !bias_kv && !key_tok) hipLaunchKernelGGL((attention_split_kernel<8, 5, false, false>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx, bias_kv);
     else PG_ATT_SPLIT(10, 5);
 #undef PG_ATT_SPLIT
   }
