@@ -471,11 +471,12 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   const int Tk = T + (bias_kv ? 1 : 0);          // keys: the T tokens + ESM-1's bias_k / bias_v
   static const int fine_ladder = [] { const char* e = getenv("PGIBBS_ATTN_LADDER"); return e ? atoi(e) : 1; }();   // 0: the coarse ladder only
   if (T <= 0) return fail(1, "attention: empty sequence");
-  // extra rungs for the plain form (no <pad> mask, no bias key: the Gibbs path): a chain of 200 residues has 13 key blocks, not 18 --
+  // extra rungs for the forms without ESM-1's bias key (the Gibbs path, and ragged batches): a chain of 200 residues has 13 key blocks, not 18 --
   // the blocks beyond T are zero-filled and masked, i.e. pure waste (and exact zeros in every sum: the bits do not depend on the rung)
 #define PG_ATT_PLAIN(KB)                                                                                       \
-  else if (fine_ladder && !bias_kv && !key_tok && Tk <= KB * 16) {                                             \
-    hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+  else if (fine_ladder && !bias_kv && Tk <= KB * 16) {                                                         \
+    if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
   }
   PG_ATT(2) PG_ATT(4) PG_ATT_PLAIN(6) PG_ATT(8) PG_ATT_PLAIN(10) PG_ATT(12) PG_ATT_PLAIN(14) PG_ATT_PLAIN(16) PG_ATT(18)
   PG_ATT_PLAIN(20) PG_ATT_PLAIN(22) PG_ATT(24) PG_ATT_PLAIN(26) PG_ATT_PLAIN(28) PG_ATT(30) PG_ATT_PLAIN(32) PG_ATT_PLAIN(34) PG_ATT(36)
