@@ -25,8 +25,11 @@ Output: ONE JSON line (rank 0) with the driver's contract plus
   strict_mode  -- (N = 1) the same workload in the parity mode (PG_PREC_FP32: split-bf16 x3 GEMMs and attention): its
                   positions/s and its measured max |logit error| against the fp32 oracle -- the mode north_star's 1e-3
                   tolerance refers to; `bf16_max_abs_logit_err` is the same measurement for the benchmarked mode
-  cpu_baseline -- the fp32 CPU oracle (numpy/OpenBLAS port of the same path; the checker, never the product) on a bounded
-                  sample, plus config 1 in full and the reference-style per-position sampling-loop cost
+  value_at_tolerance -- strict-mode positions/s with its measured max |logit error|: the throughput at north_star's 1e-3
+  cpu_baseline -- BASELINE.md 3: 8 chains x 2 Gibbs iterations of the same workload in torch CPU ops on all host cores
+                  (oracle/esm_forward_torch.py, the reference's CPU path restated: fair-esm is not installed), config 1 in full,
+                  the reference-style per-position sampling-loop cost; and the numpy fp32 oracle as the checker of the engines'
+                  logits (`logit_check`) -- the checker and the baseline, never the product
 """
 import argparse
 import ctypes
@@ -100,102 +103,132 @@ def total_flops_per_iter(cfg, n_tokens, T, n_sampled):
     return gemm_flops_per_iter(cfg, n_tokens, n_sampled) + cfg["n_layers"] * 4.0 * T * d * n_tokens + 2.0 * V * d * n_sampled
 
 
+GEMM_CLASS_PATTERNS = (            # projection -> substring of the rocprofv3 kernel name (tools/pmc_traffic.sh writes the same table
+    ("gemm_qkv", "gemm_bf16_w16_kernel<0"),            # into the JSON as "classes"; that one wins when present)
+    ("gemm_fc1", "gemm_bf16_w16_kernel<1"),
+    ("gemm_out", "gemm_bf16_pp_kernel<2, 0, 4"),
+    ("gemm_fc2", "gemm_bf16_pp_kernel<2, 0, 2"))
+
+
 def measured_gemm_traffic():
-    """Fabric (L2 <-> Infinity Cache/HBM) bytes per GEMM launch from the committed PMC passes (tools/pmc_traffic.sh:
-    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs, calibrated on the LayerNorm kernel whose traffic is known
-    exactly).  The newest profiles/rNN_hbm_traffic_pmc.json wins; None when there is none."""
+    """Fabric (L2 <-> Infinity Cache/HBM) bytes per GEMM launch of THIS workload (ESM-1b config 2) from the committed PMC passes
+    (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs of this very script, calibrated on the
+    LayerNorm kernel whose traffic is known exactly).  The newest profiles/rNN_hbm_traffic_pmc.json wins -- the ESM-MSA-1b files
+    (rNN_msa_hbm_traffic_pmc.json) are another workload and are never read here.  Returns (launch-weighted bytes per launch,
+    {projection: bytes per launch}, file name); (None, {}, None) when there is no file.  PMC counters cannot be collected from
+    inside the timed process, so this is a committed measurement of the same command, not of the run that prints it."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json"))
+                   if "_msa_" not in os.path.basename(p))
     if not paths:
-        return None, None
-    k = json.load(open(paths[-1]))["kernels"]
-    gem = [(v["launches"], v["read_MB_per_launch"] + v["write_MB_per_launch"]) for n, v in k.items()
-           if any(t in n for t in ("gemm_bf16_pp_kernel", "gemm_bf16_w4_kernel", "gemm_bf16_w16_kernel"))]      # the big-tile kernels (not the peeled panels)
-    if not gem:
-        return None, os.path.basename(paths[-1])
-    return 1e6 * sum(n * mb for n, mb in gem) / sum(n for n, _ in gem), os.path.basename(paths[-1])
+        return None, {}, None
+    doc = json.load(open(paths[-1]))
+    k = doc["kernels"]
+    classes = doc.get("classes") or {}
+    per = {}
+    for cls, pat in GEMM_CLASS_PATTERNS:
+        names = [classes[cls]] if classes.get(cls) in k else [n for n in k if pat in n]
+        if names:
+            v = k[names[0]]
+            per[cls] = {"launches": v["launches"], "read": 1e6 * v["read_MB_per_launch"], "write": 1e6 * v["write_MB_per_launch"]}
+    if not per:
+        return None, {}, os.path.basename(paths[-1])
+    n = sum(v["launches"] for v in per.values())
+    return sum(v["launches"] * (v["read"] + v["write"]) for v in per.values()) / n, per, os.path.basename(paths[-1])
 
 
-def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, target_seconds=12.0, lm_f16=None):
-    """The CPU oracle (checker, never the product) timed on a bounded sample of the same workload -- b chains x one full
-    Gibbs iteration (mask, fp32 forward, draw), linear in chains -- and used as the checker of the engines' logits on those
-    very chains.  Plus BASELINE.md section 3's two other asks: config 1 in full and the reference-style per-position loop."""
+def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, lm_f16=None, chains=8, iters=2, check_chains=2):
+    """the reference's CPU path -- fair-esm fp32 under PyTorch, all host cores -- as this repo's torch-CPU
+    restatement (oracle/esm_forward_torch.py; fair-esm itself is not installed and reference files never travel to the GPU box):
+    `chains` = 8 chains x `iters` = 2 full Gibbs iterations of config 2 (mask, the WHOLE forward incl. the LM head on every row as
+    `model(batch)["logits"]` computes it, then the reference's per-position Python draw loop), linear in chains.  Config 1 in full.
+    Separately, the numpy fp32 oracle (the checker, never the product) scores the engines' logits on `check_chains` chains."""
     import numpy as np
-    from threadpoolctl import threadpool_info
+    import torch
     from oracle import draw as odraw
+    from oracle import esm_forward_torch as eft
     from oracle.esm_forward import EsmConfig, esm1b_trunk, lm_head
     ocfg = EsmConfig(vocab=cfg["vocab"], d_model=cfg["d_model"], n_layers=cfg["n_layers"], n_heads=cfg["n_heads"],
                      d_ffn=cfg["d_ffn"], max_pos=cfg["max_positions"])
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    wt = eft.torch_state(sd)
     rng = np.random.default_rng(1234)
-    keep = {}
 
-    def one(b, T_len=L, n_pos=P, top_k=0, sample=True):
-        tok = np.concatenate([np.zeros((b, 1), np.int64), rng.integers(4, 24, (b, T_len)), np.full((b, 1), 2)], axis=1)
-        idx = np.stack([rng.choice(np.arange(1, T_len + 1), n_pos, replace=False) for _ in range(b)])
-        t0 = time.perf_counter()
-        for i in range(b):
-            tok[i, idx[i]] = cfg["mask_idx"]
-        keep["masked"] = tok.copy()
-        x = esm1b_trunk(sd, ocfg, tok)
-        rows = np.stack([x[i, idx[i]] for i in range(b)]).reshape(b * n_pos, -1)
-        logits = lm_head(sd, rows)
-        toks = odraw.draw_rows(logits, valid_idx, top_k, sample, 1.0 if sample else None, np.repeat(np.arange(b), n_pos), 0,
-                               np.tile(np.arange(n_pos), b), 0, 0)
-        for i in range(b):
-            tok[i, idx[i]] = toks[i * n_pos:(i + 1) * n_pos]
-        keep["idx"], keep["logits"] = idx, logits
-        return time.perf_counter() - t0
+    def seeds(b, T_len):
+        return np.concatenate([np.zeros((b, 1), np.int64), rng.integers(4, 24, (b, T_len)), np.full((b, 1), 2)], axis=1)
 
-    t1 = one(1)
-    b = int(max(1, min(B, round(target_seconds / max(t1, 1e-3)))))
-    t = one(b) if b > 1 else t1
-    threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-    out = {"value": b * P / t, "unit": "sampled positions/s", "cores": int(threads), "kind": "port",
-           "sample": "%d of %d chains x 1 Gibbs iteration (L=%d, P=%d), fp32 numpy/OpenBLAS oracle, %.1f s" % (b, B, L, P, t)}
+    def targets(b, T_len, n_pos, n_it):
+        return [[sorted(rng.choice(np.arange(1, T_len + 1), n_pos, replace=False).tolist()) for _ in range(b)] for _ in range(n_it)]
 
-    # the oracle as checker: logits of both engine modes at the sampled rows of those b chains
-    cfg2_logits = keep["logits"]
-    check = {"chains": b, "rows": int(b * P), "logit_std": float(keep["logits"].std())}
+    # ---- config 2 sample: `chains` chains x `iters` iterations, top_k = 0, temperature = 1, all-sampling (burnin = inf)
+    eft.gibbs_iterations(wt, ocfg, seeds(1, 16), targets(1, 16, 2, 1), valid_idx)                  # thread pool / allocator warm-up
+    tok0, tg = seeds(chains, L), targets(chains, L, P, iters)
+    t0 = time.perf_counter()
+    _, t_fwd, t_loop = eft.gibbs_iterations(wt, ocfg, tok0, tg, valid_idx, top_k=0, temperature=1.0, sample=True)
+    t = time.perf_counter() - t0
+    out = {"value": chains * P * iters / t, "unit": "sampled positions/s", "cores": int(cores), "kind": "port",
+           "sample": "%d of %d chains x %d Gibbs iterations (L=%d, P=%d; BASELINE.md section 3), fp32 torch-CPU restatement of the "
+                     "reference path (full forward + LM head on every row + per-position torch draw loop), torch.set_num_threads(%d), "
+                     "%.1f s (forward %.1f s, draw loop %.2f s); chains are independent, so the whole-batch figure is the same rate"
+                     % (chains, B, iters, L, P, cores, t, t_fwd, t_loop),
+           "seconds_per_iteration_scaled_to_%d_chains" % B: t / iters * B / chains,
+           "forward_gflops_per_s": total_flops_per_iter(cfg, chains * (L + 2), L + 2, chains * (L + 2)) * iters / t_fwd / 1e9}
+
+    # ---- the numpy oracle as CHECKER: logits of the engine modes at the sampled rows of `check_chains` masked chains
+    b = check_chains
+    tokc = seeds(b, L)
+    idx = np.stack([rng.choice(np.arange(1, L + 1), P, replace=False) for _ in range(b)])
+    for i in range(b):
+        tokc[i, idx[i]] = cfg["mask_idx"]
+    x = esm1b_trunk(sd, ocfg, tokc)
+    ref = lm_head(sd, np.stack([x[i, idx[i]] for i in range(b)]).reshape(b * P, -1))
+    check = {"chains": b, "rows": int(b * P), "logit_std": float(ref.std()), "checker": "oracle/esm_forward.py (numpy fp32)"}
+
     def dist20(lg):                                   # the distribution generate_step samples from: softmax over the valid residues
         z = lg[:, valid_idx].astype(np.float64)
         z = np.exp(z - z.max(axis=1, keepdims=True))
         return z / z.sum(axis=1, keepdims=True)
-    p_ref = dist20(keep["logits"])
+    p_ref = dist20(ref)
     for name, eng in (("bf16", lm), ("fp16", lm_f16), ("fp32", lm_strict)):
         if eng is None:
             continue
-        full = eng.forward_logits(keep["masked"])
-        got = np.stack([full[i, keep["idx"][i]] for i in range(b)]).reshape(b * P, -1)
-        err = np.abs(got - keep["logits"])
+        full = eng.forward_logits(tokc)
+        got = np.stack([full[i, idx[i]] for i in range(b)]).reshape(b * P, -1)
+        err = np.abs(got - ref)
         check[name + "_max_abs_logit_err"] = float(err.max())
         check[name + "_mean_abs_logit_err"] = float(err.mean())
         q = dist20(got)
         kl = (q * (np.log(q + 1e-300) - np.log(p_ref + 1e-300))).sum(axis=1)
-        check[name + "_argmax_agreement"] = float((got[:, valid_idx].argmax(1) == keep["logits"][:, valid_idx].argmax(1)).mean())
+        check[name + "_argmax_agreement"] = float((got[:, valid_idx].argmax(1) == ref[:, valid_idx].argmax(1)).mean())
         check[name + "_kl_sampled_dist_mean"] = float(kl.mean())
         check[name + "_kl_sampled_dist_max"] = float(kl.max())
+    got_t = eft.esm1b_forward(wt, ocfg, tokc).numpy()
+    check["torch_baseline_vs_checker_max_abs"] = float(np.abs(np.stack([got_t[i, idx[i]] for i in range(b)]).reshape(b * P, -1) - ref).max())
     out["logit_check"] = check
 
-    # BASELINE config 1 in full on the CPU: one chain, L = 25, P = 2, 20 iterations (top_k = 1, burnin = 10)
+    # ---- BASELINE config 1 in full on the CPU: one chain, L = 25, P = 2, 20 iterations (top_k = 1, burnin = 10)
+    tok1 = seeds(1, 25)
     t0 = time.perf_counter()
     for it in range(20):
-        one(1, T_len=25, n_pos=2, top_k=1, sample=it < 10)
+        tok1, _, _ = eft.gibbs_iterations(wt, ocfg, tok1, targets(1, 25, 2, 1), valid_idx, top_k=1, temperature=1.0, sample=it < 10)
     tc1 = time.perf_counter() - t0
     out["config1"] = {"cpu_positions_per_s": 40 / tc1, "cpu_ms_per_iter": 1e3 * tc1 / 20,
-                      "workload": "ESM-1b, 1 chain x L=25 (T=27), P=2, 20 iterations, top_k=1, burnin=10, all %d host threads" % threads}
+                      "workload": "ESM-1b, 1 chain x L=25 (T=27), P=2, 20 iterations, top_k=1, burnin=10, torch CPU, %d threads" % cores}
     if gpu_cfg1:
         out["config1"].update(gpu_cfg1)
 
-    # reference-style sampling loop: the reference draws position by position in Python (esm_sampler.py:225-234); the
-    # oracle's scalar generate_step stands in for it (one call per sampled position, one core)
-    rows = cfg2_logits
-    n = min(len(rows), 400)
+    # ---- reference-style sampling loop alone (BASELINE.md section 3): the per-position torch draw the reference runs in Python
+    # (esm_sampler.py:225-234), on the checker's logits
+    rows = torch.from_numpy(ref)
+    vi = torch.as_tensor(valid_idx)
+    n = min(len(ref), 400)
     t0 = time.perf_counter()
     for i in range(n):
-        odraw.generate_step(rows, i, temperature=1.0, top_k=0, sample=True, valid_idx=valid_idx, row_id=i, it=0, slot=0, seed=0)
+        eft.generate_step(rows, i, top_k=0, temperature=1.0, sample=True, valid_idx=vi)
     per = (time.perf_counter() - t0) / n
     out["reference_style_position_loop"] = {"us_per_position_one_core": 1e6 * per, "s_per_iteration_at_config2": per * B * P,
-                                            "note": "per-position Python draw loop as in esm_sampler.py:225-234, %d calls timed" % n}
+                                            "note": "per-position torch draw (topk + Categorical) as in esm_sampler.py:8-45,225-234, %d calls timed" % n}
     return out
 
 
@@ -438,17 +471,28 @@ def main():
             gf = executed_flops_per_iter()[0] * n_prof
             family = gf / (ms * 1e-3) / 1e12
             dom = max(per, key=lambda k_: parts[k_][0]) if per else None           # the kernel the iteration spends most time in
-            traffic, traffic_src = measured_gemm_traffic()
-            alg_avg = (sum(per[k_]["algorithmic_MB_per_launch"] * per[k_]["launches_per_iter"] for k_ in per)
-                       / max(1, sum(per[k_]["launches_per_iter"] for k_ in per)) * 1e6) if per else None
+            _, pmc, traffic_src = measured_gemm_traffic()
+            for k_ in per:
+                if k_ in pmc:
+                    tb = pmc[k_]["read"] + pmc[k_]["write"]
+                    per[k_].update({"measured_fabric_MB_per_launch": tb / 1e6, "measured_fabric_read_MB_per_launch": pmc[k_]["read"] / 1e6,
+                                    "traffic_ratio": tb / (per[k_]["algorithmic_MB_per_launch"] * 1e6)})
+            w_l = {k_: per[k_]["launches_per_iter"] for k_ in per}
+            alg_avg = (sum(per[k_]["algorithmic_MB_per_launch"] * w_l[k_] for k_ in per) / max(1, sum(w_l.values())) * 1e6) if per else None
+            have = [k_ for k_ in per if "measured_fabric_MB_per_launch" in per[k_]]
+            traffic = (sum(per[k_]["measured_fabric_MB_per_launch"] * w_l[k_] for k_ in have) / sum(w_l[k_] for k_ in have) * 1e6) if have else None
             kname = {"gemm_qkv": "QKV projection (gemm_bf16_w16_kernel<EPI_BF16>)", "gemm_out": "attention out-projection (gemm_bf16_pp_kernel<EPI_F32_RESID>)",
                      "gemm_fc1": "fc1 + GELU (gemm_bf16_w16_kernel<EPI_BF16_GELU>)", "gemm_fc2": "fc2 (gemm_bf16_pp_kernel<EPI_F32_RESID>)"}
             out["roofline"] = {"bound": "mfma", "kernel": kname.get(dom, "bf16 MFMA GEMM"),
                                "achieved": per[dom]["tflops"] if dom else family, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": (per[dom]["tflops"] if dom else family) / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": traffic,
-                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE+WRITE_SIZE, calibrated; %s), avg over the per-layer GEMM launches; "
-                                               "algorithmic bytes of the same launches, from the shapes: %.0f (per kernel below)"
+                               "traffic_ratio": (traffic / alg_avg) if (traffic and alg_avg) else None,
+                               "traffic_dominant_kernel": (per[dom].get("measured_fabric_MB_per_launch", 0) * 1e6 or None) if dom else None,
+                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE + WRITE_SIZE in separate --pmc passes of this script, "
+                                               "calibrated on LayerNorm; committed file %s -- PMC cannot be read from inside the timed process), "
+                                               "weighted by this run's launches per iteration over the four per-layer GEMMs; algorithmic bytes of "
+                                               "the same launches, from the shapes: %.0f; per-kernel measured / algorithmic in per_kernel[*].traffic_ratio"
                                                % (traffic_src, alg_avg or 0),
                                "avg_launch_ms": (per[dom]["avg_launch_us"] / 1e3) if dom else ms / launches,
                                "flops_per_launch": (per[dom]["gflop_per_launch"] * 1e9) if dom else gf / launches,
@@ -536,6 +580,15 @@ def main():
             out["strict_mode"]["max_abs_logit_err"] = chk.get("fp32_max_abs_logit_err")
             out["strict_mode"]["logit_std"] = chk["logit_std"]
         out["bf16_max_abs_logit_err"] = chk.get("bf16_max_abs_logit_err")
+        if "strict_mode" in out and out["strict_mode"]["max_abs_logit_err"] is not None:
+            # north_star: "within 1e-3 on emitted logits".  `value` above is the bf16-operand mode BASELINE config 2 names, which does
+            # NOT meet that tolerance; this is the throughput of the mode that does, on the same workload and weights.
+            out["value_at_tolerance"] = {"value": out["strict_mode"]["value"], "unit": "sampled positions/s",
+                                         "ms_per_step": out["strict_mode"]["ms_per_step"], "mode": "PG_PREC_FP32 (strict)",
+                                         "tolerance": 1e-3, "max_abs_logit_err": out["strict_mode"]["max_abs_logit_err"],
+                                         "meets_tolerance": bool(out["strict_mode"]["max_abs_logit_err"] < 1e-3),
+                                         "headline_mode_max_abs_logit_err": chk.get("bf16_max_abs_logit_err"),
+                                         "headline_mode_meets_tolerance": bool((chk.get("bf16_max_abs_logit_err") or 1.0) < 1e-3)}
         # BASELINE config 1 (one chain, L = 25) measured on CPU and GPU inside cpu_baseline(): also at the top level of the line
         if "config1" in out["cpu_baseline"]:
             out["config1"] = out["cpu_baseline"]["config1"]

@@ -34,6 +34,11 @@ for k in raw["FETCH_SIZE"]:
     wr = raw["WRITE_SIZE"].get(k, (0.0, 0))[0]
     out["kernels"][k] = {"launches": n, "read_MB_per_launch": fr * f_scale / 1e6, "write_MB_per_launch": wr * w_scale / 1e6,
                          "raw_FETCH_SIZE": fr, "raw_WRITE_SIZE": wr}
+# projection -> kernel name of this build (bench.py's GEMM_CLASS_PATTERNS; the JSON's table wins there)
+pats = (("gemm_qkv", "gemm_bf16_w16_kernel<0"), ("gemm_fc1", "gemm_bf16_w16_kernel<1"),
+        ("gemm_out", "gemm_bf16_pp_kernel<2, 0, 4"), ("gemm_fc2", "gemm_bf16_pp_kernel<2, 0, 2"))
+out["classes"] = {c: next((k for k in out["kernels"] if p in k), None) for c, p in pats}
+out["command"] = "bench.py --steps 1 --warmup 0 --layers 3 (config 2 shapes: 256 chains x T=258), one rocprofv3 --pmc pass per counter"
 json.dump(out, open("%s/gpurun_out/traffic_%s.json" % (root, tag), "w"), indent=1)
 for k, v in out["kernels"].items():
     print("%-70s n=%3d read %8.1f MB write %8.1f MB" % (k[:70], v["launches"], v["read_MB_per_launch"], v["write_MB_per_launch"]))
