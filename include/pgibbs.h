@@ -226,6 +226,29 @@ int pg_sample_writeback_device(void* stream, int32_t* d_tokens, int64_t n_rows, 
                                int V, const int32_t* d_idx, const int32_t* d_row_map, int64_t n_sel, int P,
                                const pg_sample_params* params, int iteration, int32_t* d_sampled_tokens);
 
+/* ---- multi-GPU tail: the one collective of a sharded job -------------------------------------------
+ * Chains / MSAs / templates are independent, so a job shards as contiguous blocks over the GPUs of a node with NO data-path
+ * collective; what the reference untokenises at the end of a batch -- the token buffer of ALL chains,
+ * src/pgen/esm_sampler.py:236-239, esm_msa_sampler.py:250-253 -- is rebuilt from the shards by one RCCL all-gather over xGMI.
+ * One process per GPU, one communicator per process.  librccl.so is opened at run time (PG_ERR_UNSUPPORTED when absent).
+ *   pg_comm_unique_id   rank 0 fills id_out[PG_COMM_ID_BYTES] (ncclGetUniqueId) and hands it to the other ranks out of band
+ *                       (environment, file, MPI, a torch.distributed store ...)
+ *   pg_comm_create      every rank, same id: joins the communicator on `device_ordinal` (ncclCommInitRank; collective)
+ *   pg_gather_tokens    d_local[rows][width] int32 of every rank -> d_out[sum(counts)][width] on every rank, rank-major (= chain
+ *                       order of contiguous shards).  counts[world] = rows of each rank (NULL: every rank has `rows`); equal
+ *                       counts gather straight into d_out, ragged ones through padded blocks.  Runs on `hip_stream` (a
+ *                       hipStream_t, NULL = the null stream), asynchronously: synchronise the stream before reading d_out on
+ *                       the host.  Order it after the engine's work (pg_engine_synchronize, or pass the engine's stream). */
+#define PG_COMM_ID_BYTES 128
+typedef struct pg_comm pg_comm;
+int pg_comm_unique_id(void* id_out);
+int pg_comm_create(int rank, int world, const void* unique_id, int device_ordinal, pg_comm** out);
+void pg_comm_destroy(pg_comm*);
+int pg_comm_rank(const pg_comm*);
+int pg_comm_world(const pg_comm*);
+int pg_gather_tokens(pg_comm*, void* hip_stream, const int32_t* d_local, int64_t rows, int width, const int64_t* counts,
+                     int32_t* d_out);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * HIP-event timing of kernel classes on the engine's stream (bench.py's roofline figure).
  * class names: "gemm", "attention", "layernorm", "embed", "head", "sample".  */

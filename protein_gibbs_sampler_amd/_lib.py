@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("PGIBBS_LIB_PATH") or os.path.join(_HERE, "lib", "libp
 PG_OK = 0
 PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_NO_DEVICE, PG_ERR_WEIGHTS, PG_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 PG_ARCH_ESM1B, PG_ARCH_MSA1B, PG_ARCH_ESM1 = 1, 2, 3
+PG_COMM_ID_BYTES = 128
 PG_PREC_BF16, PG_PREC_FP32, PG_PREC_F16 = 0, 1, 2
 INT32_MAX = 2**31 - 1
 
@@ -95,6 +96,12 @@ SIGNATURES = [
     ("pg_mask_scatter_device", c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int]),
     ("pg_sample_writeback_device", c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                                            c_int, POINTER(SampleParams), c_int, c_void_p]),
+    ("pg_comm_unique_id", c_int, [c_void_p]),
+    ("pg_comm_create", c_int, [c_int, c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    ("pg_comm_destroy", None, [c_void_p]),
+    ("pg_comm_rank", c_int, [c_void_p]),
+    ("pg_comm_world", c_int, [c_void_p]),
+    ("pg_gather_tokens", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64), c_void_p]),
     ("pg_prof_enable", c_int, [c_void_p, c_int]),
     ("pg_prof_reset", c_int, [c_void_p]),
     ("pg_prof_get", c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64)]),

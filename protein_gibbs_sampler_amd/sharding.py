@@ -129,3 +129,60 @@ def gather_tokens(dist, local_tokens, counts=None, force_padded=False):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+
+class NativeComm:
+    """The same collective behind the C ABI (include/pgibbs.h: pg_comm_*, pg_gather_tokens -- RCCL opened by the library itself,
+    no torch.distributed in the data path).  The communicator id is the only thing that travels out of band: rank 0 makes it,
+    `exchange(id_bytes_or_None) -> id_bytes` hands it to the others (default: a broadcast over an existing torch.distributed
+    group of any backend; a world of one needs no exchange)."""
+
+    def __init__(self, rank, world, device_ordinal, exchange=None):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        L = _lib.lib()
+        buf = ctypes.create_string_buffer(_lib.PG_COMM_ID_BYTES)
+        if rank == 0:
+            _lib.check(L.pg_comm_unique_id(buf))
+        if world > 1:
+            if exchange is None:
+                import torch.distributed as dist
+                box = [buf.raw if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = exchange(buf.raw if rank == 0 else None)
+            buf = ctypes.create_string_buffer(raw, _lib.PG_COMM_ID_BYTES)
+        self.rank, self.world, self.device = rank, world, device_ordinal
+        self.handle = ctypes.c_void_p()
+        _lib.check(L.pg_comm_create(rank, world, buf, device_ordinal, ctypes.byref(self.handle)))
+
+    def gather_tokens(self, local_tokens, counts=None, stream=None):
+        """local_tokens: int32 CUDA tensor [rows, width...] on this communicator's device -> [sum(counts), width...] (a torch
+        tensor only as the owner of device memory; the call takes raw pointers).  Runs on `stream` (default: torch's current
+        stream) and returns after enqueueing."""
+        import ctypes
+        import torch
+        t = local_tokens.contiguous()
+        assert t.dtype == torch.int32 and t.is_cuda and t.device.index == self.device
+        rows = t.shape[0]
+        width = int(np.prod(t.shape[1:])) if t.dim() > 1 else 1
+        counts = [rows] * self.world if counts is None else [int(c) for c in counts]
+        out = torch.empty((sum(counts),) + tuple(t.shape[1:]), dtype=torch.int32, device=t.device)
+        c_counts = (ctypes.c_int64 * self.world)(*counts)
+        s = stream if stream is not None else torch.cuda.current_stream(t.device).cuda_stream
+        self._lib.check(self._lib.lib().pg_gather_tokens(self.handle, ctypes.c_void_p(s), ctypes.c_void_p(t.data_ptr()), rows, width,
+                                                         c_counts, ctypes.c_void_p(out.data_ptr())))
+        return out
+
+    def close(self):
+        if self.handle:
+            self._lib.lib().pg_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

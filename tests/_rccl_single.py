@@ -38,6 +38,23 @@ rag = sharding.gather_tokens(dist, t, [5], force_padded=True)
 assert rag.shape == t.shape and (rag == t).all()
 print("OK gather_tokens: all_gather_into_tensor and padded all_gather")
 
+# the same collective through the C ABI (pg_comm_* / pg_gather_tokens: the library opens RCCL itself), equal and padded forms
+comm = sharding.NativeComm(0, 1, 0)
+assert _lib.lib().pg_comm_rank(comm.handle) == 0 and _lib.lib().pg_comm_world(comm.handle) == 1
+nat = comm.gather_tokens(t, [5])
+torch.cuda.synchronize()
+assert nat.device.type == "cuda" and (nat == t).all()
+os.environ["PGIBBS_GATHER_FORCE_PADDED"] = "1"
+nat2 = comm.gather_tokens(t.reshape(5, 7, 1), [5])
+torch.cuda.synchronize()
+del os.environ["PGIBBS_GATHER_FORCE_PADDED"]
+assert nat2.shape == (5, 7, 1) and (nat2.reshape(5, 7) == t).all()
+import ctypes  # noqa: E402
+bad = (ctypes.c_int64 * 1)(4)
+assert _lib.lib().pg_gather_tokens(comm.handle, None, ctypes.c_void_p(t.data_ptr()), 5, 7, bad, ctypes.c_void_p(nat.data_ptr())) == _lib.PG_ERR_INVALID
+comm.close()
+print("OK pg_gather_tokens through the C ABI (RCCL opened by libpgibbs.so)")
+
 # run_sharded through the real engine under that group == the direct call
 cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=256, n_layers=2, d_ffn=512, max_positions=64)
 sd = weights.synthetic_state_dict(cfg, seed=3, std=0.05, embed_std=0.3, ln_jitter=0.1)

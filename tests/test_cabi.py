@@ -74,3 +74,20 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     h = ctypes.c_void_p()
     assert L.pg_engine_create(ctypes.byref(cfg), None, 0, 0, 0, ctypes.byref(h)) == _lib.PG_ERR_NO_DEVICE
     assert b"no CPU fallback" in L.pg_last_error()
+
+
+def test_comm_entry_points_reject_bad_arguments_and_need_a_gpu():
+    """pg_comm_* (the C-ABI form of the one RCCL gather): argument checks run on the host; joining a communicator
+    without a GPU is PG_ERR_NO_DEVICE, never a silent single-process fallback."""
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(_lib.PG_COMM_ID_BYTES)
+    assert L.pg_comm_unique_id(None) == _lib.PG_ERR_INVALID
+    assert L.pg_comm_create(0, 1, None, 0, ctypes.byref(h)) == _lib.PG_ERR_INVALID
+    assert L.pg_comm_create(2, 2, ident, 0, ctypes.byref(h)) == _lib.PG_ERR_INVALID and b"rank" in L.pg_last_error()
+    if L.pg_device_count() == 0:
+        assert L.pg_comm_create(0, 1, ident, 0, ctypes.byref(h)) == _lib.PG_ERR_NO_DEVICE
+        assert not h.value
+    assert L.pg_gather_tokens(None, None, None, 0, 1, None, None) == _lib.PG_ERR_INVALID
+    assert L.pg_comm_rank(None) == -1 and L.pg_comm_world(None) == 0
+    L.pg_comm_destroy(None)

@@ -25,7 +25,7 @@ def test_rccl_world_size_one_collectives_and_run_sharded():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_single.py")], capture_output=True, text=True, env=_env(),
                        timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    assert "DONE" in p.stdout and p.stdout.count("OK ") == 4
+    assert "DONE" in p.stdout and p.stdout.count("OK ") == 5
 
 
 def test_bench_single_gpu_through_rccl():
