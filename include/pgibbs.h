@@ -164,7 +164,11 @@ typedef struct {
 int pg_esm_forward_logits(pg_engine*, const int32_t* tokens, int B, int T, float* logits_out);
 int pg_esm_gibbs_run(pg_engine*, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,
                      const pg_sample_params* params, float* sampled_logits, int32_t* sampled_tokens);
-/* same, every pointer device-resident (tokens stay in HBM; used by bench.py and multi-GPU drivers) */
+/* same, every pointer device-resident (tokens stay in HBM; used by bench.py and multi-GPU drivers).  Asynchronous: returns after
+ * enqueueing on the engine's stream; every buffer (incl. d_target_idx) must stay valid until pg_engine_synchronize.  Single short
+ * chains (<= 32 token rows) may run on a persistent launch whose device-wide barriers can time out when the GPU is shared; such
+ * calls are logged with a snapshot of their token rows, and the next pg_esm_gibbs_run_device / pg_engine_synchronize that sees
+ * the timeout restores the rows and runs the logged calls again on the per-layer launches (same results, one warning). */
 int pg_esm_gibbs_run_device(pg_engine*, int32_t* d_tokens_inout, int B, int T, const int32_t* d_target_idx,
                             int n_iters, int P, const pg_sample_params* params, float* d_sampled_logits,
                             int32_t* d_sampled_tokens);

@@ -97,9 +97,17 @@ int pg_engine_set_stream(pg_engine* h, void* hip_stream) {
 }
 int pg_engine_synchronize(pg_engine* h) {
   if (!h) return fail(PG_ERR_INVALID, "null engine");
-  DeviceGuard g(h->e.device);
-  PG_HIP(hipStreamSynchronize(h->e.stream));
-  return h->e.chain_check();
+  Engine& e = h->e;
+  DeviceGuard g(e.device);
+  PG_HIP(hipStreamSynchronize(e.stream));
+  // a barrier timeout of the persistent trunk inside asynchronous device-pointer calls: they were logged with their token rows and
+  // chain_check() has just run them again on the per-layer launches -- nothing for the caller to repair
+  int rc = e.chain_check();
+  if (rc && e.chain_replay_ok) {
+    e.chain_retry = false;
+    return PG_OK;
+  }
+  return rc;
 }
 int pg_engine_device(const pg_engine* h) { return h ? h->e.device : -1; }
 int pg_engine_set_job_items(pg_engine* h, int64_t job_items) {
@@ -162,8 +170,19 @@ int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T,
     return fail(PG_ERR_INVALID, "pg_esm_gibbs_run_device: null argument");
   int rc = check_params(params, h->e.cfg.vocab);
   if (rc) return rc;
-  DeviceGuard g(h->e.device);
-  return h->e.esm_gibbs_device(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
+  Engine& e = h->e;
+  DeviceGuard g(e.device);
+  if (B > 0 && n_iters > 0 && T >= 1 && e.chain_may_run(B, T)) {
+    if (*e.chain_err) {                   // an earlier asynchronous call has reported a timeout: repair before building on its tokens
+      PG_HIP(hipStreamSynchronize(e.stream));
+      rc = e.chain_check();
+      if (rc && !e.chain_replay_ok) return rc;
+      e.chain_retry = false;
+    }
+    if (e.chain_may_run(B, T) && (rc = e.chain_log_call(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens)))
+      return rc;
+  }
+  return e.esm_gibbs_device(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
 }
 
 static int esm_gibbs_run_once(pg_engine* h, int32_t* tokens_inout, int B, int T, const int32_t* target_idx, int n_iters, int P,

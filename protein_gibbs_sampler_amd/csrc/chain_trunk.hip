@@ -630,13 +630,40 @@ bool chain_trunk_ok(int M, int d_model, int d_ffn, int n_heads) {
 size_t chain_trunk_sync_bytes() { return (size_t)(CT_SLOTS + CT_MAX_GRID) * 4; }   // exit counter, pair counters, flags, slots (zeroed once)
 size_t chain_trunk_part_bytes(int M, int d_model) { return (size_t)4 * M * d_model * 4; }
 
+// One workgroup per CU, all resident at once (the barriers spin).  Nothing in an ordinary launch guarantees that, so the grid is
+// bounded per DEVICE by what the occupancy calculator says can be resident (CU count x workgroups per CU of this very kernel:
+// 512 threads, ~65 KB of LDS, <= 128 VGPRs) and kChainTrunkUnfit sends the caller to the per-layer launches when not even one
+// workgroup per CU fits.  What no query can see -- another process's persistent grid, a CU mask -- is caught by the barrier
+// timeout (Engine::chain_check).
+template <int MT, int NK>
+static int chain_trunk_grid(int device) {
+  static int cached[64];                                   // per device ordinal: 0 = not asked yet, < 0 = unfit
+  if (device < 0 || device >= 64) return -1;
+  if (cached[device] == 0) {
+    hipDeviceProp_t p;
+    int per_cu = 0;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_trunk_kernel<MT, NK>, 512, 0) != hipSuccess || per_cu < 1)
+      cached[device] = -1;
+    else
+      cached[device] = std::min(p.multiProcessorCount, CT_MAX_GRID);
+  }
+  return cached[device];
+}
+
 int launch_chain_trunk(hipStream_t s, const PgChainTrunkArgs& a, int M, int d_model) {
-  static const int n_cu = [] { hipDeviceProp_t p; int dv = 0; (void)hipGetDevice(&dv); return hipGetDeviceProperties(&p, dv) == hipSuccess ? p.multiProcessorCount : 256; }();
   static const int g_env = [] { const char* e = getenv("PGIBBS_CHAIN_TRUNK_GRID"); return e ? atoi(e) : 0; }();
-  // one workgroup per CU: all of them must be resident at once (the barriers spin), and 512 threads + ~65 KB of LDS fit any CU
-  const int G = std::min(g_env > 0 && g_env <= n_cu ? g_env : n_cu, CT_MAX_GRID);
   if (a.n_layers <= 0) return 0;
   if (a.B * a.T > M || a.T > 32 || a.T < 1) return fail(1, "chain_trunk: shape");
+  int dev = 0;
+  PG_HIP(hipGetDevice(&dev));
+  int n_cu;
+#define PG_CT_GRID(MTV, NK) n_cu = chain_trunk_grid<MTV, NK>(dev)
+  if (M == 16) { if (d_model / 256 == 4) PG_CT_GRID(1, 4); else PG_CT_GRID(1, 5); }
+  else { if (d_model / 256 == 4) PG_CT_GRID(2, 4); else PG_CT_GRID(2, 5); }
+#undef PG_CT_GRID
+  if (n_cu < 1) return kChainTrunkUnfit;
+  const int G = g_env > 0 && g_env <= n_cu ? g_env : n_cu;
   dim3 grid(G), block(512);
 #define PG_CT(MTV, NK) hipLaunchKernelGGL((chain_trunk_kernel<MTV, NK>), grid, block, 0, s, a)
 #define PG_CT_NK(MTV)                          \

@@ -94,6 +94,20 @@ struct Engine {
   // inputs are intact, to run the call again on the per-layer launches
   int chain_check();
   bool chain_disabled = false, chain_retry = false;
+  // Device-pointer Gibbs calls (pg_esm_gibbs_run_device) are asynchronous and overwrite the caller's tokens in place, so a barrier
+  // timeout is only seen after the damage.  Every such call that may take the persistent launch is therefore logged with a
+  // snapshot of its (<= 32) token rows; when a later synchronisation finds the error word set, chain_check() switches the kernel
+  // off, restores the first snapshot of every token buffer and runs the logged calls again, in order, on the per-layer launches.
+  struct ChainCall {
+    int32_t* d_tok; int B, T; const int32_t* d_idx; int n_iters, P; pg_sample_params sp; float* lg; int32_t* st; size_t snap_off;
+  };
+  std::vector<ChainCall> chain_log;
+  bool chain_replay_ok = false;                              // set by chain_check(): the logged calls were run again successfully
+  DevBuf chain_snap;
+  static constexpr size_t kChainSnapBytes = 128, kChainLogMax = 64;
+  bool chain_may_run(int B, int T) const;                    // would a forward of this shape take the persistent launch?
+  int chain_log_call(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp, float* lg,
+                     int32_t* st);
   hipGraphExec_t graph_exec = nullptr;
   std::vector<uint8_t> graph_key;
   int64_t stat_graph_captures = 0, stat_graph_replays = 0;     // pg_engine_get_stat

@@ -99,7 +99,7 @@ Engine::~Engine() {
   for (void* p : owned) (void)hipFree(p);
   DevBuf* bufs[] = {&x, &h, &qkv, &ctx, &ffn, &sel_h, &sel_g, &logits, &d_tokens, &d_idx, &d_samp_tok, &d_samp_logits,
                     &d_rowmap, &scratch, &d_iter, &tmp_idx, &tmp_out, &x_sel, &ctx_sel, &h_sel, &ffn_sel, &ffn_f32, &scores, &splitk,
-                    &chain_sync, &chain_part};
+                    &chain_sync, &chain_part, &chain_snap};
   for (DevBuf* b : bufs) b->release();
   if (chain_err) (void)hipHostFree(chain_err);
   prof.destroy();
@@ -292,8 +292,33 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
   return PG_OK;
 }
 
+bool Engine::chain_may_run(int B, int T) const {
+  return chain_layers && chain_err && !chain_disabled && T >= 1 && T <= 32 && (int64_t)B * T <= 32;
+}
+
+int Engine::chain_log_call(int32_t* d_tok, int B, int T, const int32_t* d_idx_, int n_iters, int P, const pg_sample_params* sp,
+                           float* lg, int32_t* st) {
+  int rc;
+  if (chain_log.size() >= kChainLogMax) {              // bound the log: check (and, if need be, recover) now
+    PG_HIP(hipStreamSynchronize(stream));
+    if ((rc = chain_check()) && !chain_replay_ok) return rc;
+    chain_retry = false;
+    if (chain_disabled) return PG_OK;
+  }
+  if ((rc = chain_snap.ensure(kChainSnapBytes * kChainLogMax, stream))) return rc;
+  const size_t off = chain_log.size() * kChainSnapBytes;
+  PG_HIP(hipMemcpyAsync((char*)chain_snap.p + off, d_tok, (size_t)B * T * 4, hipMemcpyDeviceToDevice, stream));
+  chain_log.push_back({d_tok, B, T, d_idx_, n_iters, P, *sp, lg, st, off});
+  return PG_OK;
+}
+
+// Call right after a synchronisation of `stream`.  PG_OK when no barrier of the persistent trunk timed out since the last check.
+// Otherwise the kernel is switched off for this engine, the logged device-pointer calls are replayed on the per-layer launches
+// (PG_OK if that was all there was to repair: pg_engine_synchronize), and a host-buffer entry point that is in flight is told to
+// run again (chain_retry + PG_ERR_HIP: its inputs are intact in the caller's buffers).
 int Engine::chain_check() {
-  if (!chain_err || !*chain_err) return PG_OK;
+  chain_replay_ok = false;
+  if (!chain_err || !*chain_err) { chain_log.clear(); return PG_OK; }
   *chain_err = 0;
   if (chain_sync.p) (void)hipMemsetAsync(chain_sync.p, 0, chain_sync.bytes, stream);
   if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; graph_key.clear(); }   // it holds the persistent launch
@@ -302,6 +327,23 @@ int Engine::chain_check() {
                     "this engine uses the per-layer launches from now on\n");
   chain_disabled = true;
   chain_retry = true;
+  if (!chain_log.empty()) {
+    std::vector<ChainCall> log;
+    log.swap(chain_log);
+    std::vector<int32_t*> seen;
+    for (const ChainCall& c : log) {
+      if (std::find(seen.begin(), seen.end(), c.d_tok) == seen.end()) {
+        seen.push_back(c.d_tok);
+        PG_HIP(hipMemcpyAsync(c.d_tok, (char*)chain_snap.p + c.snap_off, (size_t)c.B * c.T * 4, hipMemcpyDeviceToDevice, stream));
+      }
+      int rc = esm_gibbs_device(c.d_tok, c.B, c.T, c.d_idx, c.n_iters, c.P, &c.sp, c.lg, c.st);
+      if (rc) return rc;
+    }
+    PG_HIP(hipStreamSynchronize(stream));
+    chain_replay_ok = true;
+    return fail(PG_ERR_HIP, "single-chain trunk: a device-wide barrier timed out; the device-pointer calls since the last "
+                            "synchronisation were run again on the per-layer launches (their results are valid)");
+  }
   return fail(PG_ERR_HIP, "single-chain trunk: a device-wide barrier timed out (is another persistent kernel sharing this GPU? "
                           "PGIBBS_CHAIN_TRUNK=0 selects the per-layer launches); the results of this call are invalid");
 }
@@ -429,7 +471,12 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     ca.layers = chain_layers; ca.n_layers = cfg.n_layers; ca.partial_last = sel_idx ? 1 : 0; ca.B = B; ca.T = T;
     ca.x = X; ca.qkv = QKV; ca.ctx = CTX; ca.ffn = FFN; ca.part = chain_part.as<float>(); ca.sync = chain_sync.as<unsigned>();
     ca.err = chain_err; ca.eps = eps;
-    if ((rc = timed(PC_GEMM, [&] { return OPS(launch_chain_trunk, stream, ca, Mi, d); }))) return rc;
+    rc = timed(PC_GEMM, [&] { return OPS(launch_chain_trunk, stream, ca, Mi, d); });
+    if (rc == kChainTrunkUnfit) {              // the grid cannot be co-resident on this device: per-layer launches, for good
+      chain_disabled = true;
+      goto per_layer;
+    }
+    if (rc) return rc;
     {   // test hook: PGIBBS_CHAIN_TRUNK_FAULT=n makes the n-th persistent launch of the process report a barrier timeout
       static const int fault_at = [] { const char* e = getenv("PGIBBS_CHAIN_TRUNK_FAULT"); return e ? atoi(e) : 0; }();
       static int launches = 0;
@@ -439,6 +486,7 @@ int Engine::esm_trunk(const int32_t* d_tok, int B, int T, const int32_t* sel_idx
     l_first = cfg.n_layers - 1;
     attn_done = true;
   }
+per_layer:
   for (int l = l_first; l < cfg.n_layers; ++l) {
     const EsmLayer& L = esm_layers[l];
     // Hh holds LN1(x): written by the previous layer's fc2 launch (or the LayerNorm kernel) -- see resid_gemm_ln

@@ -11,6 +11,8 @@ namespace pg {
 // (defined at global scope and aliased: argument-dependent lookup on a pg:: type would make calls inside pg::opf16 ambiguous
 // with the inline default flavour)
 }  // namespace pg
+// launch_chain_trunk's answer when the persistent grid cannot be co-resident on the device (occupancy): take the per-layer launches
+constexpr int kChainTrunkUnfit = -1;
 struct PgSeqLayout { int inner_count, outer_rows, inner_rows, row_step; };
 // the persistent single-chain trunk (chain_trunk.hip): one layer's weights as device pointers, and the launch's arguments
 struct PgChainLayerW {
