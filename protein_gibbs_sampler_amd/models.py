@@ -13,27 +13,30 @@ from .alphabet import Alphabet
 from .engine import NativeMaskedLM
 
 
-def _resolve_weights(cfg, state_dict, checkpoint, filename, seed, synthetic):
+def _resolve_weights(cfg, state_dict, checkpoint, filename, seed, synthetic, explicit_config=False):
+    """-> (state dict, config).  A checkpoint file brings its own hyper-parameters (weights.config_from_checkpoint): `cfg` is the
+    wrapper's architecture and the default for files that carry none."""
     if state_dict is not None:
-        return state_dict
+        return state_dict, cfg
     path = checkpoint or _w.find_cached_checkpoint(filename)
     if path:
-        return _w.load_fair_esm_checkpoint(path, cfg)
+        return _w.load_fair_esm_checkpoint(path, cfg, return_config=True, explicit_config=explicit_config)
     if not synthetic:
         raise FileNotFoundError(
             "no %s checkpoint: pass checkpoint=<path to the fair-esm .pt file> (CLI: --checkpoint) or place it in "
             "~/.cache/torch/hub/checkpoints/.  Seeded synthetic weights of the same architecture are available only as an "
             "explicit opt-in (synthetic=True / --synthetic-weights): output sampled from them is not biologically "
             "meaningful." % filename)
-    return _w.synthetic_state_dict(cfg, seed=seed)
+    return _w.synthetic_state_dict(cfg, seed=seed), cfg
 
 
 class _Wrapper:
-    def __init__(self, cfg, alphabet, msa, state_dict, checkpoint, filename, seed, precision, synthetic):
+    def __init__(self, cfg, alphabet, msa, state_dict, checkpoint, filename, seed, precision, synthetic, explicit_config=False):
+        sd, cfg = _resolve_weights(cfg, state_dict, checkpoint, filename, seed, synthetic, explicit_config)
         self.cfg = cfg
         self.alphabet = alphabet
         self.batch_converter = alphabet.get_batch_converter(msa=msa)
-        self.model = NativeMaskedLM(cfg, _resolve_weights(cfg, state_dict, checkpoint, filename, seed, synthetic), precision)
+        self.model = NativeMaskedLM(cfg, sd, precision)
 
 
 class ESM1b(_Wrapper):
@@ -41,7 +44,7 @@ class ESM1b(_Wrapper):
 
     def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
         super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
-                         "esm1b_t33_650M_UR50S.pt", seed, precision, synthetic)
+                         "esm1b_t33_650M_UR50S.pt", seed, precision, synthetic, config is not None)
 
 
 class ESM1v(_Wrapper):
@@ -49,7 +52,7 @@ class ESM1v(_Wrapper):
 
     def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
         super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
-                         "esm1v_t33_650M_UR90S_1.pt", seed, precision, synthetic)
+                         "esm1v_t33_650M_UR90S_1.pt", seed, precision, synthetic, config is not None)
 
 
 class ESM_MSA1(_Wrapper):
@@ -57,7 +60,7 @@ class ESM_MSA1(_Wrapper):
 
     def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
         super().__init__(config or dict(_w.MSA1B_CONFIG), Alphabet(True, False), True, state_dict, checkpoint,
-                         "esm_msa1b_t12_100M_UR50S.pt", seed, precision, synthetic)
+                         "esm_msa1b_t12_100M_UR50S.pt", seed, precision, synthetic, config is not None)
 
 
 class _ESM1(_Wrapper):
@@ -66,7 +69,7 @@ class _ESM1(_Wrapper):
 
     def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
         super().__init__(config or dict(self._cfg), Alphabet(True, False, arch="ESM-1"), False, state_dict, checkpoint,
-                         self._file, seed, precision, synthetic)
+                         self._file, seed, precision, synthetic, config is not None)
 
 
 class ESM6(_ESM1):

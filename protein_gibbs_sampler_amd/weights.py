@@ -198,25 +198,96 @@ def normalise_state_dict(sd, cfg, fair_esm_layout=True):
     return out
 
 
-def load_fair_esm_checkpoint(path, cfg):
-    """Read a fair-esm `.pt` file ({"args"/"cfg": ..., "model": state dict}) as the reference does through
-    `esm.pretrained.*` (/root/reference/src/pgen/models.py:61,86)."""
+_ARCH_OF = {"roberta_large": _lib.PG_ARCH_ESM1B, "protein_bert_base": _lib.PG_ARCH_ESM1, "msa_transformer": _lib.PG_ARCH_MSA1B}
+_ARCH_NAME = {_lib.PG_ARCH_ESM1B: "ESM-1b", _lib.PG_ARCH_ESM1: "ESM-1", _lib.PG_ARCH_MSA1B: "MSA-1b"}
+
+
+def checkpoint_args(blob):
+    """The hyper-parameters a fair-esm v1 checkpoint carries ({"args": Namespace | dict}) with the `encoder_` / `decoder_` prefixes
+    dropped, as fair-esm's loader drops them before it builds the module (its lambda `pra`, esm/pretrained.py [recalled]):
+    `encoder_embed_dim` -> `embed_dim`, `decoder_layers` -> `layers`, ...  {} when the file has none."""
+    a = blob.get("args") if isinstance(blob, dict) else None
+    if a is None:
+        return {}
+    raw = dict(a) if isinstance(a, dict) else dict(vars(a))
+    out = {}
+    for k, v in raw.items():
+        for pre in ("encoder_", "decoder_"):
+            if pre in k:
+                k = "".join(k.split(pre)[1:])
+                break
+        out[k] = v
+    return out
+
+
+def config_from_checkpoint(args, state_names, base_cfg, explicit=False):
+    """The engine configuration a checkpoint asks for: `base_cfg` (the wrapper's architecture defaults) overridden by the
+    checkpoint's own hyper-parameters -- what `esm.pretrained.*` builds the module from in the reference
+    (/root/reference/src/pgen/models.py:61-86) -- instead of a fixed dict per wrapper.  Read: arch, embed_dim, layers,
+    attention_heads, ffn_embed_dim, max_positions, token_dropout, emb_layer_norm_before, final_bias, embed_positions_msa.
+    Anything the engine does not implement raises ValueError naming the flag; with explicit=True (the caller passed `config=`)
+    a disagreement between that config and the file raises too instead of silently picking one."""
+    cfg = dict(base_cfg)
+    arch = args.get("arch")
+    if arch is not None:
+        if arch not in _ARCH_OF:
+            raise ValueError("checkpoint arch %r is not one of the architectures of pgen.models (roberta_large = ESM-1b / ESM-1v, "
+                             "protein_bert_base = ESM-1, msa_transformer = ESM-MSA-1b)" % (arch,))
+        if _ARCH_OF[arch] != cfg["arch"]:
+            raise ValueError("checkpoint arch %r does not match the requested %s engine" % (arch, _ARCH_NAME[cfg["arch"]]))
+    take = {}
+    for key, name in (("embed_dim", "d_model"), ("layers", "n_layers"), ("attention_heads", "n_heads"), ("ffn_embed_dim", "d_ffn"),
+                      ("max_positions", "max_positions")):
+        if args.get(key) is not None:
+            take[name] = int(args[key])
+    esm1b = cfg["arch"] == _lib.PG_ARCH_ESM1B
+    if esm1b and "token_dropout" in args:
+        take["token_dropout"] = 1 if args["token_dropout"] else 0
+    if explicit:
+        bad = {k: (cfg[k], v) for k, v in take.items() if cfg[k] != v}
+        if bad:
+            raise ValueError("config= disagrees with the checkpoint's own hyper-parameters: %s (given, in the file)" % bad)
+    cfg.update(take)
+    if cfg["n_heads"] * 64 != cfg["d_model"]:
+        raise ValueError("checkpoint has %d heads of dimension %g: the engine's attention kernels implement head dimension 64 "
+                         "(every model of pgen.models)" % (cfg["n_heads"], cfg["d_model"] / max(1, cfg["n_heads"])))
+    has_ln_before = any(n.startswith("emb_layer_norm_before") for n in state_names)
+    if cfg["arch"] in (_lib.PG_ARCH_ESM1B, _lib.PG_ARCH_MSA1B):
+        # fair-esm decides this flag from the tensors (`has_emb_layer_norm_before`), not from args
+        if args.get("emb_layer_norm_before") is False or not has_ln_before:
+            raise ValueError("checkpoint was trained without emb_layer_norm_before: the %s engine always applies it (every released "
+                             "ESM-1b / ESM-1v / ESM-MSA-1b checkpoint has it)" % _ARCH_NAME[cfg["arch"]])
+        if args.get("final_bias") is False:
+            raise ValueError("final_bias=False: the engine's LM head adds lm_head.bias")
+    elif has_ln_before or args.get("emb_layer_norm_before"):
+        raise ValueError("ESM-1 checkpoint with emb_layer_norm_before: the ESM-1 engine has no embedding LayerNorms")
+    if cfg["arch"] == _lib.PG_ARCH_MSA1B and args.get("embed_positions_msa") is False:
+        raise ValueError("embed_positions_msa=False: the MSA engine adds msa_position_embedding (esm_msa1b_t12_100M_UR50S has it)")
+    if cfg["arch"] != _lib.PG_ARCH_ESM1B and args.get("token_dropout"):
+        raise ValueError("token_dropout=True in a %s checkpoint: only the ESM-1b architecture implements it" % _ARCH_NAME[cfg["arch"]])
+    n_layers_seen = 1 + max([int(m.group(1)) for m in (re.match(r"layers\.(\d+)\.", n) for n in state_names) if m] or [-1])
+    if n_layers_seen and n_layers_seen != cfg["n_layers"]:
+        if "n_layers" in take or explicit:
+            raise ValueError("checkpoint holds %d layers but its hyper-parameters say %d" % (n_layers_seen, cfg["n_layers"]))
+        cfg["n_layers"] = n_layers_seen
+    return cfg
+
+
+def load_fair_esm_checkpoint(path, cfg, return_config=False, explicit_config=False):
+    """Read a fair-esm `.pt` file ({"args": ..., "model": state dict}) as the reference does through `esm.pretrained.*`
+    (/root/reference/src/pgen/models.py:61,86).  `cfg` gives the architecture (and the defaults of a file without `args`); sizes
+    and flags come from the checkpoint's own hyper-parameters (config_from_checkpoint).  return_config=True -> (state dict, cfg)."""
     import torch
     blob = torch.load(path, map_location="cpu", weights_only=False)
     sd = blob["model"] if isinstance(blob, dict) and "model" in blob else blob
-    arch = None
-    if isinstance(blob, dict):
-        a = blob.get("args")
-        arch = a.get("arch") if isinstance(a, dict) else getattr(a, "arch", None)
-        if arch is None and isinstance(blob.get("cfg"), dict):
-            arch = blob["cfg"].get("model", {}).get("arch") if isinstance(blob["cfg"].get("model"), dict) else None
-    want_msa = cfg["arch"] == _lib.PG_ARCH_MSA1B
-    if arch is not None and (arch == "msa_transformer") != want_msa:
-        raise ValueError("checkpoint arch %r does not match the requested %s engine" % (arch, "MSA-1b" if want_msa else "ESM-1b"))
-    if arch is not None and (arch == "protein_bert_base") != (cfg["arch"] == _lib.PG_ARCH_ESM1):
-        raise ValueError("checkpoint arch %r does not match the requested %s engine"
-                         % (arch, "ESM-1" if cfg["arch"] == _lib.PG_ARCH_ESM1 else "ESM-1b / MSA-1b"))
-    return normalise_state_dict(sd, cfg, fair_esm_layout=True)
+    args = checkpoint_args(blob)
+    if not args and isinstance(blob, dict) and isinstance(blob.get("cfg"), dict) and isinstance(blob["cfg"].get("model"), dict):
+        raise ValueError("checkpoint in fair-esm's v2 layout (ESM-2): not one of the models of pgen.models")
+    is_msa = cfg["arch"] == _lib.PG_ARCH_MSA1B
+    names = [_swap_row_column(_strip_fair_esm_prefixes(k)) if is_msa else _strip_fair_esm_prefixes(k) for k in sd]
+    cfg2 = config_from_checkpoint(args, names, cfg, explicit=explicit_config)
+    out = normalise_state_dict(sd, cfg2, fair_esm_layout=True)
+    return (out, cfg2) if return_config else out
 
 
 def to_fair_esm_checkpoint_layout(sd, cfg):

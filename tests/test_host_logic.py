@@ -354,3 +354,73 @@ def test_esm1_alphabet_and_checkpoint_layout(tmp_path):
     t = weights.sinusoidal_positions(10, 128, 1)
     assert (t[1] == 0).all() and np.allclose(t[0, :64], 0) and np.allclose(t[0, 64:], 1)
     assert abs(t[5, 63] - np.sin(5e-4)) < 1e-6
+
+
+def _args_pt(path, sd, cfg, arch, **args):
+    import argparse
+    import torch
+    from protein_gibbs_sampler_amd import weights
+    disk = {k: torch.from_numpy(v) for k, v in weights.to_fair_esm_checkpoint_layout(sd, cfg).items()}
+    torch.save({"model": disk, "args": argparse.Namespace(arch=arch, **args)}, path)
+
+
+def test_checkpoint_hyper_parameters_come_from_the_file(tmp_path):
+    """The reference builds each model from the checkpoint's own `args` (esm.pretrained.*, /root/reference/src/pgen/models.py:61-86).
+    The loader reads embed_dim / layers / attention_heads / ffn_embed_dim / max_positions / token_dropout (with fair-esm's
+    `encoder_` prefix dropped) instead of a fixed dict per wrapper: an ESM-1v-style file whose sizes differ from ESM-1b's loads
+    with ITS sizes; a file without args falls back to the wrapper's defaults + the layer count found in the state dict."""
+    from protein_gibbs_sampler_amd import weights
+    file_cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=3, d_ffn=384, max_positions=40, token_dropout=0)
+    sd = weights.synthetic_state_dict(file_cfg, seed=1)
+    path = tmp_path / "v.pt"
+    _args_pt(path, sd, file_cfg, "roberta_large", encoder_embed_dim=128, encoder_layers=3, encoder_attention_heads=2,
+             encoder_ffn_embed_dim=384, max_positions=40, token_dropout=False, emb_layer_norm_before=True, final_bias=True)
+    got, cfg = weights.load_fair_esm_checkpoint(str(path), dict(weights.ESM1B_CONFIG), return_config=True)
+    assert (cfg["d_model"], cfg["n_layers"], cfg["n_heads"], cfg["d_ffn"], cfg["max_positions"], cfg["token_dropout"]) == (128, 3, 2, 384, 40, 0)
+    assert set(got) == set(sd) and all(np.array_equal(got[k], sd[k]) for k in sd)       # token_dropout off: <mask> row NOT zeroed
+    # an explicit config= that contradicts the file is an error, not a silent pick
+    with pytest.raises(ValueError, match="disagrees.*d_ffn"):
+        weights.load_fair_esm_checkpoint(str(path), weights.make_config(file_cfg, d_ffn=256), explicit_config=True)
+    assert weights.load_fair_esm_checkpoint(str(path), file_cfg, explicit_config=True).keys() == sd.keys()
+    # no args at all: wrapper defaults, layer count from the tensors
+    import torch
+    blob = torch.load(path, weights_only=False)
+    torch.save({"model": blob["model"]}, path)
+    base = weights.make_config(weights.ESM1B_CONFIG, d_model=128, d_ffn=384, max_positions=40)          # n_layers = 33 by default
+    _, cfg = weights.load_fair_esm_checkpoint(str(path), base, return_config=True)
+    assert cfg["n_layers"] == 3
+
+
+@pytest.mark.parametrize("arch,base,args,msg", [
+    ("roberta_large", "ESM1B", dict(emb_layer_norm_before=False), "emb_layer_norm_before"),
+    ("roberta_large", "ESM1B", dict(final_bias=False), "final_bias"),
+    ("roberta_large", "ESM1B", dict(encoder_attention_heads=4), "head dimension 64"),
+    ("roberta_large", "ESM1B", dict(encoder_layers=5), "holds 2 layers"),
+    ("msa_transformer", "MSA1B", dict(embed_positions_msa=False), "embed_positions_msa"),
+    ("msa_transformer", "MSA1B", dict(token_dropout=True), "token_dropout"),
+    ("protein_bert_base", "ESM1_T6", dict(emb_layer_norm_before=True), "embedding LayerNorms"),
+    ("esm2_t33", "ESM1B", dict(), "not one of the architectures"),
+])
+def test_checkpoint_flags_the_engine_does_not_implement_raise(tmp_path, arch, base, args, msg):
+    """...and raise by NAME -- not as a KeyError about missing tensors three layers down."""
+    from protein_gibbs_sampler_amd import weights
+    cfg = weights.make_config(getattr(weights, base + "_CONFIG"), d_model=128, n_layers=2, d_ffn=256, max_positions=40,
+                              **({"max_msa_rows": 8} if base == "MSA1B" else {}))
+    sd = weights.synthetic_state_dict(cfg, seed=2)
+    path = tmp_path / "f.pt"
+    _args_pt(path, sd, cfg, arch, **args)
+    with pytest.raises(ValueError, match=msg):
+        weights.load_fair_esm_checkpoint(str(path), cfg)
+
+
+def test_checkpoint_without_embedding_layernorm_is_named(tmp_path):
+    """fair-esm decides emb_layer_norm_before from the TENSORS (has_emb_layer_norm_before); a roberta_large file without them
+    used to die with 'missing 2 tensors'."""
+    import torch
+    from protein_gibbs_sampler_amd import weights
+    cfg = weights.make_config(weights.ESM1B_CONFIG, d_model=128, n_layers=2, d_ffn=256, max_positions=40)
+    sd = {k: v for k, v in weights.synthetic_state_dict(cfg, seed=2).items() if not k.startswith("emb_layer_norm_before")}
+    path = tmp_path / "n.pt"
+    _args_pt(path, sd, cfg, "roberta_large")
+    with pytest.raises(ValueError, match="without emb_layer_norm_before"):
+        weights.load_fair_esm_checkpoint(str(path), cfg)
