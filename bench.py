@@ -150,10 +150,27 @@ def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, lm_f16=No
     from oracle.esm_forward import EsmConfig, esm1b_trunk, lm_head
     ocfg = EsmConfig(vocab=cfg["vocab"], d_model=cfg["d_model"], n_layers=cfg["n_layers"], n_heads=cfg["n_heads"],
                      d_ffn=cfg["d_ffn"], max_pos=cfg["max_positions"])
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     wt = eft.torch_state(sd)
     rng = np.random.default_rng(1234)
+    # Threads: the fastest count on THIS host, found by a sweep over one layer of the same batch -- not blindly "all of them":
+    # on the 256-logical-CPU hosts of the MI355X boxes torch's OpenMP pool collapses past ~32 threads (8 x 258 tokens, 4 layers:
+    # 16 threads 877 GFLOP/s, 64: 425, 256: 22 -- profiles/r05_cpu_baseline_thread_sweep.txt), so all-cores would flatter the GPU.
+    one = EsmConfig(vocab=ocfg.vocab, d_model=ocfg.d_model, n_layers=1, n_heads=ocfg.n_heads, d_ffn=ocfg.d_ffn, max_pos=ocfg.max_pos)
+    tok_sweep = np.concatenate([np.zeros((chains, 1), np.int64), rng.integers(4, 24, (chains, L)), np.full((chains, 1), 2)], axis=1)
+    sweep, n_cpu = {}, os.cpu_count() or 1
+    for nt in sorted({min(n_cpu, c) for c in (4, 8, 16, 32, 64, 128, 256)}):
+        torch.set_num_threads(nt)
+        eft.esm1b_forward(wt, one, tok_sweep[:1, :16])
+        best = float("inf")
+        for _ in range(2):
+            t0 = time.perf_counter()
+            eft.esm1b_forward(wt, one, tok_sweep)
+            best = min(best, time.perf_counter() - t0)
+        sweep[nt] = best
+        if sweep[nt] > 2.5 * min(sweep.values()):
+            break                                                  # past the knee: more threads only get slower
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
 
     def seeds(b, T_len):
         return np.concatenate([np.zeros((b, 1), np.int64), rng.integers(4, 24, (b, T_len)), np.full((b, 1), 2)], axis=1)
@@ -169,9 +186,10 @@ def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, lm_f16=No
     t = time.perf_counter() - t0
     out = {"value": chains * P * iters / t, "unit": "sampled positions/s", "cores": int(cores), "kind": "port",
            "sample": "%d of %d chains x %d Gibbs iterations (L=%d, P=%d; BASELINE.md section 3), fp32 torch-CPU restatement of the "
-                     "reference path (full forward + LM head on every row + per-position torch draw loop), torch.set_num_threads(%d), "
+                     "reference path (full forward + LM head on every row + per-position torch draw loop), %d threads = the fastest count of a sweep on this host, "
                      "%.1f s (forward %.1f s, draw loop %.2f s); chains are independent, so the whole-batch figure is the same rate"
                      % (chains, B, iters, L, P, cores, t, t_fwd, t_loop),
+           "host_logical_cpus": n_cpu, "thread_sweep_s_per_layer": {str(k_): round(v_, 4) for k_, v_ in sweep.items()},
            "seconds_per_iteration_scaled_to_%d_chains" % B: t / iters * B / chains,
            "forward_gflops_per_s": total_flops_per_iter(cfg, chains * (L + 2), L + 2, chains * (L + 2)) * iters / t_fwd / 1e9}
 

@@ -29,6 +29,10 @@ extern "C" {
 #define PG_ERR_NO_DEVICE 3 /* no MI355X visible -- the product never falls back to a CPU path */
 #define PG_ERR_WEIGHTS 4   /* missing / mis-shaped tensor in the state dict */
 #define PG_ERR_UNSUPPORTED 5
+#define PG_ERR_RANGE 6     /* non-finite logits reached the draw / log-probability / output stage: a 16-bit tensor of the forward left
+                              the fp16 range in PG_PREC_F16 (or the weights hold NaN / inf).  Host-buffer entry points report it
+                              BEFORE they overwrite the caller's buffers, so the call can be repeated on a PG_PREC_BF16 engine;
+                              device-pointer entry points report it at pg_engine_synchronize */
 
 const char* pg_version(void);
 const char* pg_last_error(void);
@@ -82,7 +86,9 @@ typedef struct pg_engine pg_engine;
 #define PG_PREC_BF16 0 /* bf16 MFMA operands, fp32 accumulate, fp32 residual stream (throughput mode) */
 #define PG_PREC_F16 2  /* the throughput mode with IEEE fp16 operands instead of bf16 (same kernels, same MFMA rate; 3 more mantissa
                           bits: logit error 8x smaller, profiles/r04_rounding_ablation.txt).  No saturation: a 16-bit tensor of the
-                          forward beyond +-65504 would become inf -- use PG_PREC_BF16 for such checkpoints. */
+                          forward beyond +-65504 becomes inf, the next LayerNorm / softmax turns it into NaN logits, and the call
+                          returns PG_ERR_RANGE instead of drawing from them -- use PG_PREC_BF16 for such checkpoints (the Python
+                          layer's precision="auto" does that by itself: weights.py / engine.py). */
 #define PG_PREC_FP32 1 /* strict parity mode: every matrix product (projections, q.k^T, P.v) as three bf16 MFMA products on
                           (hi, lo) splits of both operands (lo.hi + hi.lo + hi.hi, fp32 accumulate); fp32 softmax, LayerNorm
                           and residual stream; ~3x slower, logits within 1e-3 of the fp32 oracle.  The FFN's GELU is

@@ -32,9 +32,11 @@ def add_engine_args(parser):
     parser.add_argument("--synthetic-weights", dest="synthetic_weights", action="store_true",
                         help="opt in to seeded random weights of the model's architecture when no checkpoint is available "
                              "(benchmarks / plumbing tests: the output is not biologically meaningful)")
-    parser.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
-                        help="bf16 = throughput mode; fp16 = the same kernels with fp16 operands (same speed, 8x smaller logit "
-                             "error; no saturation beyond +-65504); fp32 = parity mode (split-bf16 GEMMs and attention)")
+    parser.add_argument("--precision", default="auto", choices=["auto", "bf16", "fp16", "fp32"],
+                        help="auto = fp16 operands with a range guard (weights scanned, one probe forward, non-finite logits "
+                             "detected per call: falls back to bf16 with one warning); bf16 = the benchmarked throughput mode; "
+                             "fp16 = the same kernels with fp16 operands, no fallback (8x smaller logit error than bf16, ~3 %% "
+                             "slower); fp32 = parity mode (split-bf16 GEMMs and attention, logits within 1e-3 of fp32)")
     parser.add_argument("--seed", type=int, default=None, help="seed random and torch (positions and token draws) for reproducible output")
 
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PGIBBS_LIB_PATH") or os.path.join(_HERE, "lib", "libpgibbs.so")     # override: A/B runs of two builds
 
 PG_OK = 0
-PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_NO_DEVICE, PG_ERR_WEIGHTS, PG_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
+PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_NO_DEVICE, PG_ERR_WEIGHTS, PG_ERR_UNSUPPORTED, PG_ERR_RANGE = 1, 2, 3, 4, 5, 6
 PG_ARCH_ESM1B, PG_ARCH_MSA1B, PG_ARCH_ESM1 = 1, 2, 3
 PG_COMM_ID_BYTES = 128
 PG_PREC_BF16, PG_PREC_FP32, PG_PREC_F16 = 0, 1, 2

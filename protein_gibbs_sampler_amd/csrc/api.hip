@@ -51,6 +51,15 @@ int check_idx_table(const int32_t* idx, size_t n, int width, const char* who) {
   }
   return PG_OK;
 }
+// full-logit entry points: the rows just copied to the host are scanned there (a few MB; the Gibbs and log-probability entry
+// points are covered by their kernels, Engine::range_err)
+int check_finite(Engine& e, const float* v, size_t n) {
+  float worst = 0.f;
+  for (size_t i = 0; i < n; ++i) worst = fmaxf(worst, fabsf(v[i]) <= 3.0e38f ? 0.f : 1.f);
+  if (worst == 0.f) return PG_OK;
+  *e.range_err = 1;
+  return e.range_check();
+}
 bool has_token(const int32_t* tokens, size_t n, int32_t id) {
   for (size_t i = 0; i < n; ++i)
     if (tokens[i] == id) return true;
@@ -105,9 +114,9 @@ int pg_engine_synchronize(pg_engine* h) {
   int rc = e.chain_check();
   if (rc && e.chain_replay_ok) {
     e.chain_retry = false;
-    return PG_OK;
+    rc = PG_OK;
   }
-  return rc;
+  return rc ? rc : e.range_check();
 }
 int pg_engine_device(const pg_engine* h) { return h ? h->e.device : -1; }
 int pg_engine_set_job_items(pg_engine* h, int64_t job_items) {
@@ -147,7 +156,8 @@ static int esm_forward_logits_once(pg_engine* h, const int32_t* tokens, int B, i
   if ((rc = e.head(nullptr, nullptr, 1, T, M, e.logits.as<float>()))) return rc;
   PG_HIP(hipMemcpyAsync(logits_out, e.logits.p, (size_t)M * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
-  return e.chain_check();
+  if ((rc = e.chain_check())) return rc;
+  return check_finite(e, logits_out, (size_t)M * e.cfg.vocab);
 }
 // The persistent single-chain trunk is an optimistic fast path: when one of its barriers timed out (Engine::chain_check) the
 // call's inputs are still intact in the caller's buffers, so it runs once more, now on the per-layer launches.
@@ -210,10 +220,10 @@ static int esm_gibbs_run_once(pg_engine* h, int32_t* tokens_inout, int B, int T,
                           sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
                           sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
   if (rc) return rc;
-  if (e.chain_err) {                       // before the caller's token buffer (input AND output) is overwritten
-    PG_HIP(hipStreamSynchronize(e.stream));
-    if ((rc = e.chain_check())) return rc;
-  }
+  // before the caller's token buffer (input AND output) is overwritten: a timed-out persistent launch is re-run by the caller
+  // macro, non-finite logits (PG_ERR_RANGE) leave the input intact for a caller that retries in another precision
+  PG_HIP(hipStreamSynchronize(e.stream));
+  if ((rc = e.finish_check())) return rc;
   PG_HIP(hipMemcpyAsync(tokens_inout, e.d_tokens.p, tok_bytes, hipMemcpyDeviceToHost, e.stream));
   if (sampled_logits && n_draws)
     PG_HIP(hipMemcpyAsync(sampled_logits, e.d_samp_logits.p, n_draws * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
@@ -247,7 +257,7 @@ int pg_msa_forward_logits(pg_engine* h, const int32_t* tokens, int B, int R, int
   if ((rc = e.head(nullptr, nullptr, 1, C, M, e.logits.as<float>()))) return rc;
   PG_HIP(hipMemcpyAsync(logits_out, e.logits.p, (size_t)M * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
-  return PG_OK;
+  return check_finite(e, logits_out, (size_t)M * e.cfg.vocab);
 }
 
 int pg_msa_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int R, int C, const int32_t* target_idx, int n_iters,
@@ -272,6 +282,8 @@ int pg_msa_gibbs_run(pg_engine* h, int32_t* tokens_inout, int B, int R, int C, c
                           sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
                           sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
   if (rc) return rc;
+  PG_HIP(hipStreamSynchronize(e.stream));
+  if ((rc = e.range_check())) return rc;             // before the caller's tokens are overwritten
   PG_HIP(hipMemcpyAsync(tokens_inout, e.d_tokens.p, tok_bytes, hipMemcpyDeviceToHost, e.stream));
   if (sampled_logits && n_draws)
     PG_HIP(hipMemcpyAsync(sampled_logits, e.d_samp_logits.p, n_draws * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
@@ -337,6 +349,8 @@ int pg_msa_gibbs_single_batch_run(pg_engine* h, int32_t* tokens_inout, int B, in
                            n_steps, P_max, params, sampled_logits ? e.d_samp_logits.as<float>() : nullptr,
                            sampled_tokens ? e.d_samp_tok.as<int32_t>() : nullptr);
   if (rc) return rc;
+  PG_HIP(hipStreamSynchronize(e.stream));
+  if ((rc = e.range_check())) return rc;             // before the caller's tokens are overwritten
   PG_HIP(hipMemcpyAsync(tokens_inout, e.d_tokens.p, tok_bytes, hipMemcpyDeviceToHost, e.stream));
   if (sampled_logits && n_draws)
     PG_HIP(hipMemcpyAsync(sampled_logits, e.d_samp_logits.p, n_draws * e.cfg.vocab * 4, hipMemcpyDeviceToHost, e.stream));
@@ -395,10 +409,10 @@ static int forward_logprobs(Engine& e, bool msa, const int32_t* tokens, int B, i
   if (rc) return rc;
   if ((rc = e.head(e.d_idx.as<int32_t>(), e.d_rowmap.as<int32_t>(), P, C, n, e.logits.as<float>()))) return rc;
   if ((rc = launch_logprob_gather(e.stream, e.logits.as<float>(), e.cfg.vocab, 1, C, e.d_idx.as<int32_t>(), e.d_rowmap.as<int32_t>(),
-                                  e.d_samp_tok.as<int32_t>(), n_sel, P, e.d_samp_logits.as<float>()))) return rc;
+                                  e.d_samp_tok.as<int32_t>(), n_sel, P, e.d_samp_logits.as<float>(), e.range_err))) return rc;
   PG_HIP(hipMemcpyAsync(out, e.d_samp_logits.p, (size_t)n * 4, hipMemcpyDeviceToHost, e.stream));
   PG_HIP(hipStreamSynchronize(e.stream));
-  return e.chain_check();
+  return e.finish_check();
 }
 
 int pg_esm_forward_logprobs(pg_engine* h, const int32_t* tokens, int B, int T, const int32_t* row_of, const int32_t* idx,

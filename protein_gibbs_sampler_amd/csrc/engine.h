@@ -108,6 +108,11 @@ struct Engine {
   bool chain_may_run(int B, int T) const;                    // would a forward of this shape take the persistent launch?
   int chain_log_call(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp, float* lg,
                      int32_t* st);
+  // host-pinned word the draw / log-probability kernels set when a logit row is not finite (an fp16 operand that overflowed
+  // upstream, or broken weights).  After a stream synchronisation: PG_ERR_RANGE once, the word cleared.
+  unsigned* range_err = nullptr;
+  int range_check();
+  int finish_check() { int rc = chain_check(); return rc ? rc : range_check(); }      // right after a stream synchronisation
   hipGraphExec_t graph_exec = nullptr;
   std::vector<uint8_t> graph_key;
   int64_t stat_graph_captures = 0, stat_graph_replays = 0;     // pg_engine_get_stat

@@ -102,6 +102,7 @@ Engine::~Engine() {
                     &chain_sync, &chain_part, &chain_snap};
   for (DevBuf* b : bufs) b->release();
   if (chain_err) (void)hipHostFree(chain_err);
+  if (range_err) (void)hipHostFree(range_err);
   prof.destroy();
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -288,8 +289,19 @@ int Engine::init(const pg_model_config* c, const pg_tensor* tensors, int n_tenso
     PG_HIP(hipHostMalloc((void**)&chain_err, sizeof(unsigned), hipHostMallocMapped));
     *chain_err = 0;
   }
+  PG_HIP(hipHostMalloc((void**)&range_err, sizeof(unsigned), hipHostMallocMapped));
+  *range_err = 0;
   PG_HIP(hipStreamSynchronize(stream));
   return PG_OK;
+}
+
+int Engine::range_check() {
+  if (!range_err || !*range_err) return PG_OK;
+  *range_err = 0;
+  return fail(PG_ERR_RANGE, precision == PG_PREC_F16
+                                ? "non-finite logits: a 16-bit tensor of the forward left the fp16 range (+-65504) -- run this model with "
+                                  "precision bf16 (or fp32); the results of this call are invalid"
+                                : "non-finite logits (NaN / inf in the weights or an overflow in the forward); the results of this call are invalid");
 }
 
 bool Engine::chain_may_run(int B, int T) const {
@@ -617,7 +629,7 @@ int Engine::esm_gibbs_device(int32_t* d_tok, int B, int T, const int32_t* d_idx_
     float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)it * n_draws * V : logits.as<float>();
     if ((r = pruned ? head(nullptr, nullptr, 1, 1, n_draws, lg, x_sel.as<float>()) : head(idx_it, nullptr, P, T, n_draws, lg))) return r;
     int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)it * n_draws : nullptr;
-    return timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, T, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, dit ? 0 : it, st, dit); });
+    return timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, T, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, dit ? 0 : it, st, dit, range_err); });
   };
 
   // Launch-bound regime (few tokens: ~270 launches of a few microseconds each): capture ONE iteration as a hipGraph and
@@ -846,7 +858,7 @@ int Engine::msa_gibbs_device(int32_t* d_tok, int B, int R, int C, const int32_t*
     float* lg = d_samp_logits_ ? d_samp_logits_ + (size_t)it * n_draws * V : logits.as<float>();
     if ((rc = pruned ? head(nullptr, nullptr, 1, 1, n_draws, lg, x_sel.as<float>()) : head(idx_it, nullptr, P, C, n_draws, lg))) return rc;
     int32_t* st = d_samp_tok_ ? d_samp_tok_ + (size_t)it * n_draws : nullptr;
-    if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, it, st); }))) return rc;
+    if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg, V, 1, idx_it, nullptr, n_sel_rows, P, sp, it, st, nullptr, range_err); }))) return rc;
   }
   return PG_OK;
 }
@@ -922,7 +934,7 @@ int Engine::msa_single_device(int32_t* d_tok, int B, int R, int C, int mask_row,
       pg_sample_params p = sp[b];
       p.burnin = step_sample_flag_host[s] ? 0x7fffffff : 0;   // sample=(pass_num < burn_in), esm_msa_sampler.py:143
       if ((rc = timed(PC_SAMPLE, [&] { return launch_sample_writeback(stream, d_tok, C, lg + (size_t)b * P_max * V, V, 1, idx_s + (size_t)b * P_max,
-                                                                      d_tgt_map + b, 1, P_max, &p, s, st ? st + (size_t)b * P_max : nullptr); }))) return rc;
+                                                                      d_tgt_map + b, 1, P_max, &p, s, st ? st + (size_t)b * P_max : nullptr, nullptr, range_err); }))) return rc;
     }
   }
   return PG_OK;

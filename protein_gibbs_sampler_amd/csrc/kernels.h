@@ -61,11 +61,12 @@ int launch_iter_counter(hipStream_t st, int32_t* d_iter, bool set, int value);
 size_t graph_state_bytes();
 int launch_graph_state(hipStream_t st, int32_t* d_iter, int iteration, const pg_sample_params* p);
 int launch_logprob_gather(hipStream_t st, const float* logits, int V, int compact, int width, const int32_t* idx,
-                          const int32_t* row_map, const int32_t* targets, int64_t n_sel, int P, float* out);
+                          const int32_t* row_map, const int32_t* targets, int64_t n_sel, int P, float* out,
+                          unsigned* nonfinite = nullptr);     // nonfinite: device-visible word set to 1 when a logit row holds NaN / inf
 int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_t* idx, const int32_t* row_map,
                         int64_t n_sel, int P, int mask_idx, const int32_t* d_iter = nullptr);
 int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const float* logits, int V, int compact,
                             const int32_t* idx, const int32_t* row_map, int64_t n_sel, int P, const pg_sample_params* p,
-                            int iteration, int32_t* sampled_tokens, const int32_t* d_iter = nullptr);
+                            int iteration, int32_t* sampled_tokens, const int32_t* d_iter = nullptr, unsigned* nonfinite = nullptr);
 
 }  // namespace pg

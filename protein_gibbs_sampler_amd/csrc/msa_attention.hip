@@ -294,7 +294,7 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
                                   int order_bh) {
   if (B == 0 || R == 0) return 0;
   if (C <= 0) return fail(1, "row attention: empty alignment");
-  if (C > 576) return fail(5, "row attention: alignments wider than 575 columns take the fp32-scores path");
+  if (C > 576) return fail(5, "row attention: alignments wider than 576 token columns (<cls> + 575 residues) take the fp32-scores path");
   const int n_bh = B * H;
   // workgroup width: 4 waves up to 64 columns, beyond that the widest the register budget of the score fragments allows
   // (9 waves up to 288 keys, 8 beyond).  The row loop is split over workgroups when the (msa, head, query-chunk) grid alone
@@ -325,7 +325,7 @@ int launch_msa_row_attention_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx,
 #undef PG_ROWATT
 #undef PG_ROWATT_K
   else {
-    return fail(5, "row attention: alignments wider than 575 columns take the fp32-scores path");
+    return fail(5, "row attention: alignments wider than 576 token columns (<cls> + 575 residues) take the fp32-scores path");
   }
   PG_HIP(hipGetLastError());
   return 0;

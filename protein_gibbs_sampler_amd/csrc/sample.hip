@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
                                                               const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ row_map, int64_t n_sel, int P,
                                                               SampleArgs a, int32_t* __restrict__ sampled_tokens,
-                                                              const int32_t* __restrict__ d_iter) {
+                                                              const int32_t* __restrict__ d_iter, unsigned* nonfinite) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n_sel * P) return;   // wave-uniform
@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256) void sample_writeback_kernel(int32_t* __restri
   float v = 0.f;
   if (mine) {
     v = row[my_valid];
+    // a non-finite logit (an overflowed fp16 operand upstream: inf -> NaN through the next LayerNorm) is reported, not sampled
+    // from silently: the engine's entry points return PG_ERR_RANGE (Engine::range_check)
+    if (nonfinite && !(fabsf(v) <= 3.0e38f)) *nonfinite = 1u;
     if (a.use_temp) v = v / a.temperature;
   }
   // stable descending rank of every valid entry
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void logprob_gather_kernel(const float* __rest
                                                             const int32_t* __restrict__ idx,
                                                             const int32_t* __restrict__ row_map,
                                                             const int32_t* __restrict__ targets, int64_t n_sel, int P,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, unsigned* nonfinite) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_sel * P) return;
   const int pos = idx[i];
@@ -189,15 +192,18 @@ __global__ __launch_bounds__(256) void logprob_gather_kernel(const float* __rest
   for (int v = 1; v < V; ++v) mx = fmaxf(mx, row[v]);
   float sum = 0.f;
   for (int v = 0; v < V; ++v) sum += expf(row[v] - mx);
-  out[i] = row[targets[i]] - mx - logf(sum);
+  const float lp = row[targets[i]] - mx - logf(sum);
+  if (nonfinite && !(fabsf(mx) <= 3.0e38f)) *nonfinite = 1u;      // NaN or inf anywhere in the row ends up in mx or in lp
+  if (nonfinite && lp != lp) *nonfinite = 1u;
+  out[i] = lp;
 }
 
 int launch_logprob_gather(hipStream_t st, const float* logits, int V, int compact, int width, const int32_t* idx,
-                          const int32_t* row_map, const int32_t* targets, int64_t n_sel, int P, float* out) {
+                          const int32_t* row_map, const int32_t* targets, int64_t n_sel, int P, float* out, unsigned* nonfinite) {
   const int64_t n = n_sel * P;
   if (n == 0) return 0;
   hipLaunchKernelGGL(logprob_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logits, V, compact, width, idx,
-                     row_map, targets, n_sel, P, out);
+                     row_map, targets, n_sel, P, out, nonfinite);
   PG_HIP(hipGetLastError());
   return 0;
 }
@@ -254,7 +260,7 @@ int launch_mask_scatter(hipStream_t st, int32_t* tokens, int width, const int32_
 
 int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const float* logits, int V, int compact,
                             const int32_t* idx, const int32_t* row_map, int64_t n_sel, int P, const pg_sample_params* p,
-                            int iteration, int32_t* sampled_tokens, const int32_t* d_iter) {
+                            int iteration, int32_t* sampled_tokens, const int32_t* d_iter, unsigned* nonfinite) {
   if (p->n_valid < 1 || p->n_valid > 32) return fail(1, "sample: n_valid must be in 1..32");
   for (int j = 0; j < p->n_valid; ++j)
     if (p->valid_idx[j] < 0 || p->valid_idx[j] >= V) return fail(1, "sample: valid_idx out of range");
@@ -262,7 +268,7 @@ int launch_sample_writeback(hipStream_t st, int32_t* tokens, int width, const fl
   if (n == 0) return 0;
   const SampleArgs a = make_sample_args(p, iteration);
   hipLaunchKernelGGL(sample_writeback_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, tokens, width, logits, V,
-                     compact, idx, row_map, n_sel, P, a, sampled_tokens, d_iter);      // one wave per draw
+                     compact, idx, row_map, n_sel, P, a, sampled_tokens, d_iter, nonfinite);      // one wave per draw
   PG_HIP(hipGetLastError());
   return 0;
 }

@@ -14,13 +14,95 @@ import numpy as np
 from . import _lib
 
 
+FP16_MAX = 65504.0
+
+
+def fp16_weights_ok(state_dict):
+    """Can every tensor be stored as IEEE fp16 without overflow?  (finite, |w| <= 65504; one pass, no copies)"""
+    for name, a in state_dict.items():
+        a = np.asarray(a)
+        if a.size and not (np.isfinite(a.max()) and np.isfinite(a.min()) and max(float(a.max()), -float(a.min())) <= FP16_MAX):
+            return False, name
+    return True, None
+
+
 class NativeMaskedLM:
+    """precision: "bf16" (the benchmarked throughput mode), "fp16" (the same kernels with fp16 operands: 8x closer to the fp32
+    reference for ~3 % of the speed, but no range beyond +-65504), "fp32" (strict parity mode), or "auto" (default of models.* and
+    the command-line front ends since round 5) = fp16 WITH A GUARD:
+      1. the weights are scanned when the object is built -- a tensor that does not fit fp16 selects bf16;
+      2. when the engine is created on a GPU one small probe forward must come back finite;
+      3. every later call reports non-finite logits as PG_ERR_RANGE before it overwrites anything the caller owns (and the MSA
+         engine answers PG_ERR_UNSUPPORTED for the shapes its fp16 kernels lack: <pad> batches, alignments wider than 576
+         columns); the host-buffer methods below then rebuild the engine with bf16 operands, warn ONCE, and run the call again.
+    The engine never leaves fp16 silently and never produces NaN-derived draws.  Device-pointer callers (bench.py, plug-in loops)
+    get the error from pg_engine_synchronize and choose themselves."""
+
     def __init__(self, cfg, state_dict, precision="bf16"):
         self.cfg = dict(cfg)
         self.state_dict = state_dict       # name -> float32 ndarray (host master copy)
+        self.auto = precision == "auto"
+        if self.auto:
+            ok, worst = fp16_weights_ok(state_dict)
+            precision = "fp16" if ok else "bf16"
+            if not ok:
+                import warnings
+                warnings.warn("precision='auto': tensor %r does not fit IEEE fp16 (|w| > 65504 or not finite) -- using bf16 operands" % worst)
         self.precision = {"bf16": _lib.PG_PREC_BF16, "fp32": _lib.PG_PREC_FP32, "fp16": _lib.PG_PREC_F16}[precision]
         self._h = None
+        self._job_items = 0
         self.device = "cpu"
+
+    @property
+    def precision_name(self):
+        return {_lib.PG_PREC_BF16: "bf16", _lib.PG_PREC_FP32: "fp32", _lib.PG_PREC_F16: "fp16"}[self.precision]
+
+    # ---- the fp16 guard of precision="auto" -------------------------------------------------------
+    def _fall_back_to_bf16(self, err):
+        import warnings
+        warnings.warn("precision='auto': the fp16-operand engine reported %r -- rebuilding it with bf16 operands; this and all "
+                      "later calls run in bf16" % (err.msg,))
+        dev = self.device
+        self._destroy()
+        self.precision = _lib.PG_PREC_BF16
+        self.device = "cpu"
+        self.to(dev)
+        if self._job_items:
+            self.set_job_items(self._job_items)
+
+    def _guarded(self, fn, inout=None):
+        """Run fn() (which must read self.handle when called).  In auto mode on fp16 operands a range / unsupported-shape error
+        rebuilds the engine in bf16 and runs fn() again, with the in/out buffer restored to what the caller passed."""
+        if not (self.auto and self.precision == _lib.PG_PREC_F16):
+            return fn()
+        keep = inout.copy() if inout is not None else None
+        try:
+            return fn()
+        except _lib.PgError as e:
+            if e.code not in (_lib.PG_ERR_RANGE, _lib.PG_ERR_UNSUPPORTED):
+                raise
+            self._fall_back_to_bf16(e)
+            if keep is not None:
+                inout[...] = keep
+            return fn()
+
+    def _probe(self):
+        """One small forward right after the engine exists: a checkpoint whose activations leave the fp16 range is moved to bf16
+        here, before any user call (PGIBBS_F16_PROBE=0 skips it)."""
+        import os
+        if os.environ.get("PGIBBS_F16_PROBE", "1") in ("", "0"):
+            return
+        c = self.cfg
+        n = max(4, min(64, c["max_positions"] - 2))
+        body = 4 + (np.arange(2 * n).reshape(2, n) * 7 + 3) % 20           # the 20 amino-acid ids 4..23, deterministic
+        body[0, 1::9] = c["mask_idx"]
+        if self.is_msa:
+            tok = np.concatenate([np.full((2, 1), c["cls_idx"]), body], axis=1)[None].repeat(2, axis=1).reshape(1, 4, n + 1)
+        elif c["arch"] == _lib.PG_ARCH_ESM1:
+            tok = np.concatenate([np.full((2, 1), c["cls_idx"]), body], axis=1)
+        else:
+            tok = np.concatenate([np.full((2, 1), c["cls_idx"]), body, np.full((2, 1), c["eos_idx"])], axis=1)
+        self.forward_logits(tok)
 
     # ---- nn.Module-ish protocol used by the samplers -------------------------------------
     def eval(self):
@@ -51,6 +133,8 @@ class NativeMaskedLM:
         h = ctypes.c_void_p()
         _lib.check(L.pg_engine_create(ctypes.byref(c), arr, len(names), int(m.group(1)), self.precision, ctypes.byref(h)))
         self._h = h
+        if self.auto and self.precision == _lib.PG_PREC_F16:
+            self._probe()
         return self
 
     def cuda(self, device=0):
@@ -95,11 +179,11 @@ class NativeMaskedLM:
         if self.is_msa:
             B, R, C = tok.shape
             out = np.empty((B, R, C, V), dtype=np.float32)
-            _lib.check(L.pg_msa_forward_logits(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(out)))
+            self._guarded(lambda: _lib.check(L.pg_msa_forward_logits(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(out))))
         else:
             B, T = tok.shape
             out = np.empty((B, T, V), dtype=np.float32)
-            _lib.check(L.pg_esm_forward_logits(self.handle, _lib.ptr(tok), B, T, _lib.ptr(out)))
+            self._guarded(lambda: _lib.check(L.pg_esm_forward_logits(self.handle, _lib.ptr(tok), B, T, _lib.ptr(out))))
         return out
 
     def forward_logprobs(self, tokens, row_of, idx, targets):
@@ -113,12 +197,12 @@ class NativeMaskedLM:
         L = _lib.lib()
         if self.is_msa:
             B, R, C = tok.shape
-            _lib.check(L.pg_msa_forward_logprobs(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(row_of), _lib.ptr(idx),
-                                                 _lib.ptr(targets), n_sel, P, _lib.ptr(out)))
+            self._guarded(lambda: _lib.check(L.pg_msa_forward_logprobs(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(row_of), _lib.ptr(idx),
+                                                                       _lib.ptr(targets), n_sel, P, _lib.ptr(out))))
         else:
             B, T = tok.shape
-            _lib.check(L.pg_esm_forward_logprobs(self.handle, _lib.ptr(tok), B, T, _lib.ptr(row_of), _lib.ptr(idx),
-                                                 _lib.ptr(targets), n_sel, P, _lib.ptr(out)))
+            self._guarded(lambda: _lib.check(L.pg_esm_forward_logprobs(self.handle, _lib.ptr(tok), B, T, _lib.ptr(row_of), _lib.ptr(idx),
+                                                                       _lib.ptr(targets), n_sel, P, _lib.ptr(out))))
         return out
 
     # ---- whole Gibbs loops -----------------------------------------------------------------
@@ -134,12 +218,12 @@ class NativeMaskedLM:
         L = _lib.lib()
         if self.is_msa:
             B, R, C = tok.shape
-            _lib.check(L.pg_msa_gibbs_run(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(idx), n_iters, P, ctypes.byref(params),
-                                          _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None))
+            self._guarded(lambda: _lib.check(L.pg_msa_gibbs_run(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(idx), n_iters, P, ctypes.byref(params),
+                                                                _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None)), tok)
         else:
             B, T = tok.shape
-            _lib.check(L.pg_esm_gibbs_run(self.handle, _lib.ptr(tok), B, T, _lib.ptr(idx), n_iters, P, ctypes.byref(params),
-                                          _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None))
+            self._guarded(lambda: _lib.check(L.pg_esm_gibbs_run(self.handle, _lib.ptr(tok), B, T, _lib.ptr(idx), n_iters, P, ctypes.byref(params),
+                                                                _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None)), tok)
         return lg, st
 
     def gibbs_single_run(self, tokens, mask_row, target_row, step_idx, step_sample, params, want_logits=False,
@@ -167,10 +251,9 @@ class NativeMaskedLM:
         V = self.cfg["vocab"]
         lg = np.empty((n_steps, B, P, V), dtype=np.float32) if want_logits else None
         st = np.empty((n_steps, B, P), dtype=np.int32) if want_tokens else None
-        _lib.check(_lib.lib().pg_msa_gibbs_single_batch_run(self.handle, _lib.ptr(tok), B, R, C, mask_row, target_row, _lib.ptr(idx),
-                                                           _lib.ptr(flags), n_steps, P, arr,
-                                                           _lib.ptr(lg) if want_logits else None,
-                                                           _lib.ptr(st) if want_tokens else None))
+        self._guarded(lambda: _lib.check(_lib.lib().pg_msa_gibbs_single_batch_run(
+            self.handle, _lib.ptr(tok), B, R, C, mask_row, target_row, _lib.ptr(idx), _lib.ptr(flags), n_steps, P, arr,
+            _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None)), tok)
         return lg, st
 
     def get_stat(self, name):
@@ -196,4 +279,5 @@ class NativeMaskedLM:
     def set_job_items(self, n):
         """Batch items (chains / MSAs) of the whole multi-GPU job the following calls are shards of; 0 = whole jobs again
         (pgibbs.h pg_engine_set_job_items: keeps every shard bit-identical with the single-GPU run)."""
+        self._job_items = int(n)
         _lib.check(_lib.lib().pg_engine_set_job_items(self.handle, int(n)))

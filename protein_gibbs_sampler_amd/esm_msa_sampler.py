@@ -312,14 +312,20 @@ class ESM_MSA_sampler():
             reformatted = [[(str(i), self.clean_seed_seq(seq)) for i, seq in enumerate(msa)] for msa in msa_list]
             _, _, tokens = self.model.batch_converter(reformatted)          # [n, R_max, C_max], <pad> around the smaller MSAs
             n, R, C = tokens.shape
+            # the reference's own shape check (:353): the widest target row fills the padded width
+            assert max(len(msa[target_index]) for msa in msa_list) == C - range_start
+            # Row scored per MSA.  target_index >= 0: row target_index, as the reference.  target_index < 0 counts from the END OF
+            # EACH MSA (as the masked path below and generate_single do).  On a list of equal depths that is the reference's
+            # tokens[:, target_index]; on a ragged list the reference reads that row of the PADDED tensor -- a <pad> row for every
+            # shallower MSA, whose "likelihoods" are those of <pad> tokens -- a deliberate deviation.
+            rows_of = [target_index if target_index >= 0 else len(msa) + target_index for msa in msa_list]
             for batch_start in range(0, n, max(1, batch_size)):
                 chunk = tokens[batch_start:batch_start + max(1, batch_size)]
                 nb = chunk.shape[0]
                 pos_of, orig = [], []
                 for i in range(nb):
                     msa = msa_list[batch_start + i]
-                    tr = target_index if target_index >= 0 else R + target_index      # tokens[:, target_index] of the PADDED tensor (:370)
-                    o = chunk[i, tr].numpy()
+                    o = chunk[i, rows_of[batch_start + i]].numpy()
                     end = len(msa[target_index]) + range_start
                     pos_of.append([p_ for p_ in range(range_start, end) if count_gaps or int(o[p_]) not in gap_tokens])
                     orig.append(o)
@@ -329,8 +335,8 @@ class ESM_MSA_sampler():
                 for i, pos in enumerate(pos_of):
                     idx[i, :len(pos)] = pos
                     tgt[i, :len(pos)] = orig[i][pos]
-                tr = target_index if target_index >= 0 else R + target_index
-                lp = _gibbs.score_positions(self.model.model, chunk, np.arange(nb) * R + tr, idx, tgt, self.device)
+                row_of = np.arange(nb) * R + np.asarray(rows_of[batch_start:batch_start + nb])
+                lp = _gibbs.score_positions(self.model.model, chunk, row_of, idx, tgt, self.device)
                 for i in range(nb):
                     msa = msa_list[batch_start + i]
                     denom = len(msa[target_index]) - (0 if count_gaps else sum(msa[target_index].count(g) for g in ESM_MSA_GAP_CHARACTERS))
@@ -339,6 +345,8 @@ class ESM_MSA_sampler():
                     for p_ in range(len(pos_of[i])):
                         likelihood_sum = np.float32(likelihood_sum + lp[i, p_])
                         likelihood_list.append(float(lp[i, p_]))
+                    if denom == 0:                       # all-gap target row with count_gaps=False: the reference's 0.0 / 0
+                        raise ZeroDivisionError("float division by zero")
                     yield (float(likelihood_sum / np.float32(denom)), likelihood_list)
             return
         for msa in msa_list:
@@ -347,6 +355,7 @@ class ESM_MSA_sampler():
             R = one.shape[1]
             tr = target_index % R
             seq_len = len(msa[target_index])
+            assert seq_len == one.shape[2] - range_start              # the reference's shape check (:353-355)
             denom = seq_len - (0 if count_gaps else sum(msa[target_index].count(g) for g in ESM_MSA_GAP_CHARACTERS))
             end = seq_len + range_start
             orig = one[0, tr].numpy()
@@ -374,4 +383,6 @@ class ESM_MSA_sampler():
                         likelihood_sum = np.float32(likelihood_sum + lp[i, p])
                         likelihood_list.append(float(lp[i, p]))
             assert len(likelihood_list) == denom
+            if denom == 0:
+                raise ZeroDivisionError("float division by zero")
             yield (float(likelihood_sum / np.float32(denom)), likelihood_list)

@@ -42,7 +42,7 @@ class _Wrapper:
 class ESM1b(_Wrapper):
     """esm1b_t33_650M_UR50S (models.py:59-62)."""
 
-    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="auto", config=None, synthetic=False):
         super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
                          "esm1b_t33_650M_UR50S.pt", seed, precision, synthetic, config is not None)
 
@@ -50,7 +50,7 @@ class ESM1b(_Wrapper):
 class ESM1v(_Wrapper):
     """esm1v_t33_650M_UR90S (models.py:64-67): same architecture as ESM-1b, different weights."""
 
-    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="auto", config=None, synthetic=False):
         super().__init__(config or dict(_w.ESM1B_CONFIG), Alphabet(True, True), False, state_dict, checkpoint,
                          "esm1v_t33_650M_UR90S_1.pt", seed, precision, synthetic, config is not None)
 
@@ -58,7 +58,7 @@ class ESM1v(_Wrapper):
 class ESM_MSA1(_Wrapper):
     """esm_msa1b_t12_100M_UR50S (models.py:84-88) with the reference's patched MSA batch converter."""
 
-    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="auto", config=None, synthetic=False):
         super().__init__(config or dict(_w.MSA1B_CONFIG), Alphabet(True, False), True, state_dict, checkpoint,
                          "esm_msa1b_t12_100M_UR50S.pt", seed, precision, synthetic, config is not None)
 
@@ -67,7 +67,7 @@ class _ESM1(_Wrapper):
     """ESM-1 family (models.py:69-82): the 35-token "ESM-1" alphabet, <cls> prepended, no <eos>."""
     _cfg, _file = None, None
 
-    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="bf16", config=None, synthetic=False):
+    def __init__(self, state_dict=None, checkpoint=None, seed=0, precision="auto", config=None, synthetic=False):
         super().__init__(config or dict(self._cfg), Alphabet(True, False, arch="ESM-1"), False, state_dict, checkpoint,
                          self._file, seed, precision, synthetic, config is not None)
 

@@ -20,7 +20,7 @@ model_map = {"esm1b": models.ESM1b, "esm6": models.ESM6, "esm12": models.ESM12, 
 def main(input_h, output_p, args, sampler=None):
     if sampler is None:
         sampler = ESM_sampler(model_map[args.model](checkpoint=getattr(args, "checkpoint", None),
-                                                    precision=getattr(args, "precision", "bf16"),
+                                                    precision=getattr(args, "precision", "auto"),
                                                     synthetic=getattr(args, "synthetic_weights", False)), device=args.device)
     with open(output_p / "specification.tsv", "w") as output_h:
         for line in input_h:

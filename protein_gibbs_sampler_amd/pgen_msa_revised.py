@@ -45,12 +45,25 @@ def build_template_alignment(template_name, template_seq, reference_seqs, refere
     return alignment, apply_gap_threshold(alignment, gap_percent_threshold), 0
 
 
-def _writes_output(sampler):
-    """Every process writes its own `output_path` -- unless ONE job is being split over the torch.distributed ranks
-    (sampler.shard_over_ranks / PGIBBS_SHARD_OVER_RANKS with world size > 1): every rank then holds the full result and rank 0
-    writes it.  A process group that merely exists (each rank sampling its OWN templates) does not silence anybody."""
-    ctx = sharding.dist_context() if sharding.sharding_requested(getattr(sampler, "shard_over_ranks", False)) else None
-    return ctx is None or ctx.rank == 0
+def _output_path_for_this_process(sampler, output_path):
+    """Where this process writes, or None.  ONE job split over the torch.distributed ranks (sampler.shard_over_ranks /
+    PGIBBS_SHARD_OVER_RANKS with world size > 1): every rank holds the full result and rank 0 alone writes `output_path`.  A
+    process group that merely exists (each rank sampling its OWN templates) silences nobody -- but ranks > 0 write
+    `<output_path>.rank<r>`: handed the same path (the usual torchrun script), all ranks would otherwise truncate and
+    interleave into one file, and asking the other ranks what path they were given would need a collective that ranks running
+    independent jobs cannot be assumed to join."""
+    if sharding.sharding_requested(getattr(sampler, "shard_over_ranks", False)):
+        ctx = sharding.dist_context()
+        return output_path if ctx is None or ctx.rank == 0 else None
+    try:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else 0
+    except ImportError:
+        rank = 0
+    if rank == 0:
+        return output_path
+    warnings.warn(f"rank {rank} of a torch.distributed group without shard_over_ranks: writing {output_path}.rank{rank}")
+    return f"{output_path}.rank{rank}"
 
 
 def pgen_msa(templates_path, references_path, output_path, seqs_per_template, keep_identical, steps, passes, burn_in, device,
@@ -65,12 +78,13 @@ def pgen_msa(templates_path, references_path, output_path, seqs_per_template, ke
     with tempfile.NamedTemporaryFile(delete=False, mode="w") as tmp:
         write_sequential_fasta(tmp, references)
         reference_db_path = tmp.name
-    writer = _writes_output(sampler)
+    my_output = _output_path_for_this_process(sampler, output_path)
     ctx = sharding.dist_context() if sharding.sharding_requested(getattr(sampler, "shard_over_ranks", False)) else None
     # jobs per generate_single_batch call: `template_batch` alignments share a forward; a sharded run hands every rank that many
     chunk_jobs = max(1, template_batch) * (ctx.world if ctx is not None else 1)
-    outfile = open(output_path, "w") if writer else None
+    outfile = None
     try:
+        outfile = open(my_output, "w") if my_output else None       # inside the try: a bad path must not leak the scratch FASTA
         reference_seqs = dict(zip(*parse_fasta(reference_db_path, return_names=True)))
         # The reference calls generate_single once per template and requested sequence, in this order, and prints each sequence
         # as soon as it exists (/root/reference/src/pgen/pgen_msa_revised.py:107-115, flush=True).  Here the (template, i) jobs are

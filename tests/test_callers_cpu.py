@@ -193,14 +193,14 @@ class _RecordingSampler:
         return [m[kw["target_index"]] for m in msas]
 
 
-def _run_pgen_msa_revised(tmp_path, monkeypatch, sampler, n_templates=5, seqs_per_template=2, template_batch=4):
+def _run_pgen_msa_revised(tmp_path, monkeypatch, sampler, n_templates=5, seqs_per_template=2, template_batch=4, output=None):
     from _standin import fake_generate_alignment, fake_run_phmmer
     monkeypatch.setattr(pgen_msa_revised, "run_phmmer", fake_run_phmmer)
     monkeypatch.setattr(pgen_msa_revised, "generate_alignment", fake_generate_alignment)
     t, r, o = tmp_path / "t.fasta", tmp_path / "r.fasta", tmp_path / "o.fasta"
     t.write_text("".join(">t%d\nMKV%sLA\n" % (i, "ACDEF"[i % 5]) for i in range(n_templates)))
     r.write_text(">a\nMKVALA\n>b\nMKVCLA\n>c\nMRVDLA\n")
-    pgen_msa_revised.pgen_msa(str(t), str(r), str(o), seqs_per_template, True, 3, 1, 1, "cuda:0", "esm_msa1", 3, 0.0, 1.53, 1,
+    pgen_msa_revised.pgen_msa(str(t), str(r), output or str(o), seqs_per_template, True, 3, 1, 1, "cuda:0", "esm_msa1", 3, 0.0, 1.53, 1,
                               legacy=True, sampler=sampler, template_batch=template_batch)
     return o
 
@@ -224,15 +224,36 @@ def test_pgen_msa_revised_keeps_finished_chunks_when_a_late_one_fails(tmp_path, 
 
 
 def test_pgen_msa_revised_every_rank_writes_unless_one_job_is_sharded(monkeypatch):
-    """a process group that merely exists must not silence ranks > 0 (each runs its OWN job by default)."""
+    """a process group that merely exists must not silence ranks > 0 (each runs its OWN job by default).  ADVICE r04:
+    ...and they must not all truncate and interleave into ONE file when they were handed the same path: ranks > 0 write
+    `<path>.rank<r>`.  A job sharded over the ranks is written by rank 0 alone."""
+    import torch.distributed as dist
     from protein_gibbs_sampler_amd import sharding
 
     class Ctx:
         rank, world = 1, 2
     monkeypatch.setattr(sharding, "dist_context", lambda: Ctx())
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda *a: Ctx.rank)
     s = _RecordingSampler()
-    assert pgen_msa_revised._writes_output(s)                     # rank 1, sharding off -> writes its own file
+    with pytest.warns(UserWarning, match="rank 1"):
+        assert pgen_msa_revised._output_path_for_this_process(s, "o.fasta") == "o.fasta.rank1"     # rank 1, sharding off: its own file
     s.shard_over_ranks = True
-    assert not pgen_msa_revised._writes_output(s)                 # rank 1 of a sharded job -> rank 0 writes
+    assert pgen_msa_revised._output_path_for_this_process(s, "o.fasta") is None                   # rank 1 of a sharded job: rank 0 writes
     Ctx.rank = 0
-    assert pgen_msa_revised._writes_output(s)
+    assert pgen_msa_revised._output_path_for_this_process(s, "o.fasta") == "o.fasta"
+    s.shard_over_ranks = False
+    assert pgen_msa_revised._output_path_for_this_process(s, "o.fasta") == "o.fasta"
+
+
+def test_pgen_msa_revised_bad_output_path_leaves_no_scratch_fasta(tmp_path, monkeypatch):
+    """the output file is opened inside the try block -- a path that cannot be opened still removes the scratch
+    reference FASTA in the finally."""
+    import glob
+    import tempfile
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    before = set(glob.glob(str(tmp_path / "tmp*")))
+    with pytest.raises(OSError):
+        _run_pgen_msa_revised(tmp_path, monkeypatch, _RecordingSampler(), output=str(tmp_path / "no_such_dir" / "o.fasta"))
+    assert set(glob.glob(str(tmp_path / "tmp*"))) == before

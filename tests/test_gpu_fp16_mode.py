@@ -156,3 +156,102 @@ def test_fp16_gibbs_run_draws_replay_through_the_oracle():
         rows = run["sampled_logits"][it].reshape(-1, 33)
         toks = odraw.draw_rows(rows, sampler.valid_aa_idx, 3, it < 2, 0.9, np.repeat(np.arange(6), 5), it, np.tile(np.arange(5), 6), 0, 99)
         assert (toks == run["sampled_tokens"][it].reshape(-1)).all()
+
+
+# ---- precision="auto": fp16 operands behind a range guard (ADVICE r04 pg_common.h:57) ------------------------
+_AUTO_CFG = dict(d_model=256, n_layers=3, d_ffn=512, max_positions=128)
+
+
+def _auto_setup(scale_fc1=1.0, poison=None):
+    cfg = weights.make_config(weights.ESM1B_CONFIG, **_AUTO_CFG)
+    sd = weights.synthetic_state_dict(cfg, seed=21, std=0.05, embed_std=0.3, ln_jitter=0.1)
+    sd = {k: v.copy() for k, v in sd.items()}
+    sd["layers.1.fc1.weight"] *= np.float32(scale_fc1)
+    if poison:
+        sd[poison][0] = 1e5
+    tok = np.concatenate([np.zeros((3, 1)), np.random.default_rng(2).integers(4, 24, (3, 40)), np.full((3, 1), 2)], axis=1).astype(np.int32)
+    tok[1, 5] = tok[2, 17] = 32
+    return cfg, sd, tok
+
+
+def test_auto_precision_is_fp16_on_ordinary_weights():
+    """models.* default since round 5: fp16 operands (8x closer to the fp32 reference than bf16), no warning, probe passed."""
+    cfg, sd, tok = _auto_setup()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lm = models.ESM1b(state_dict=sd, config=cfg).model.to("cuda:0")
+        got = lm.forward_logits(tok)
+    assert lm.auto and lm.precision_name == "fp16"
+    want = esm1b_forward(sd, EsmConfig(d_model=256, n_layers=3, n_heads=4, d_ffn=512, max_pos=128), tok)
+    bf = models.ESM1b(state_dict=sd, config=cfg, precision="bf16").model.to("cuda:0").forward_logits(tok)
+    e16, ebf = np.abs(got - want).max(), np.abs(bf - want).max()
+    print("\nauto (fp16) %.2e vs bf16 %.2e from the fp32 oracle" % (e16, ebf))
+    assert e16 < ebf / 3
+
+
+def test_auto_precision_weight_scan_selects_bf16():
+    cfg, sd, tok = _auto_setup(poison="layers.0.fc2.bias")
+    with pytest.warns(UserWarning, match="layers.0.fc2.bias.*does not fit IEEE fp16"):
+        lm = models.ESM1b(state_dict=sd, config=cfg).model
+    assert lm.precision_name == "bf16"
+    assert np.isfinite(lm.to("cuda:0").forward_logits(tok)).all()
+
+
+def test_auto_precision_probe_moves_an_overflowing_checkpoint_to_bf16():
+    """fc1 weights that fit fp16 (max ~ 2e4) but drive GELU(fc1) past 65504: the probe forward at .to() sees non-finite logits,
+    the engine is rebuilt with bf16 operands, ONE warning; results are those of a bf16 engine bit for bit."""
+    cfg, sd, tok = _auto_setup(scale_fc1=1e5)
+    assert np.abs(sd["layers.1.fc1.weight"]).max() < 65504
+    with pytest.warns(UserWarning) as rec:
+        lm = models.ESM1b(state_dict=sd, config=cfg).model.to("cuda:0")
+        got = lm.forward_logits(tok)
+    assert len([w for w in rec if "rebuilding it with bf16" in str(w.message)]) == 1
+    assert lm.precision_name == "bf16" and np.isfinite(got).all()
+    bf = models.ESM1b(state_dict=sd, config=cfg, precision="bf16").model.to("cuda:0").forward_logits(tok)
+    assert np.array_equal(got.view(np.uint32), bf.view(np.uint32))
+
+
+def test_auto_precision_falls_back_inside_a_call_and_restores_the_tokens(monkeypatch):
+    """Without the probe (PGIBBS_F16_PROBE=0: stands for an overflow only some later input triggers) the Gibbs call itself reports
+    PG_ERR_RANGE before it writes the caller's tokens; the wrapper rebuilds the engine in bf16, restores the tokens and runs the
+    call again: same tokens and emitted logits as a bf16 engine, one warning."""
+    monkeypatch.setenv("PGIBBS_F16_PROBE", "0")
+    cfg, sd, tok = _auto_setup(scale_fc1=1e5)
+    table = np.stack([np.stack([np.random.default_rng(9 + i).choice(np.arange(1, 41), 4, replace=False) for _ in range(3)]) for i in range(2)]).astype(np.int32)
+    params = _lib.make_sample_params(True, 32, 0, float("inf"), 1.0, list(range(4, 24)), rng_seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lm = models.ESM1b(state_dict=sd, config=cfg).model.to("cuda:0")          # no probe, no warning yet
+    assert lm.precision_name == "fp16"
+    t_auto = tok.copy()
+    with pytest.warns(UserWarning, match="rebuilding it with bf16") as rec:
+        lg_auto, _ = lm.gibbs_run(t_auto, table, params, want_logits=True)
+    assert len(rec) == 1 and lm.precision_name == "bf16"
+    ref = models.ESM1b(state_dict=sd, config=cfg, precision="bf16").model.to("cuda:0")
+    t_ref = tok.copy()
+    lg_ref, _ = ref.gibbs_run(t_ref, table, params, want_logits=True)
+    assert np.array_equal(t_auto, t_ref) and np.array_equal(lg_auto.view(np.uint32), lg_ref.view(np.uint32))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                           # stays on bf16: no second warning
+        lm.forward_logits(tok)
+
+
+def test_explicit_fp16_reports_the_overflow_instead_of_sampling_from_nan():
+    """precision="fp16" has no fallback: forward, Gibbs and log-probability entry points all return PG_ERR_RANGE, the caller's
+    token buffer untouched."""
+    cfg, sd, tok = _auto_setup(scale_fc1=1e5)
+    lm = models.ESM1b(state_dict=sd, config=cfg, precision="fp16").model.to("cuda:0")
+    with pytest.raises(_lib.PgError) as ei:
+        lm.forward_logits(tok)
+    assert ei.value.code == _lib.PG_ERR_RANGE and "fp16 range" in ei.value.msg
+    table = np.tile(np.array([3, 9], dtype=np.int32), (2, 3, 1))
+    params = _lib.make_sample_params(True, 32, 0, float("inf"), 1.0, list(range(4, 24)), rng_seed=3)
+    t = tok.copy()
+    with pytest.raises(_lib.PgError) as ei:
+        lm.gibbs_run(t, table, params)
+    assert ei.value.code == _lib.PG_ERR_RANGE and np.array_equal(t, tok)
+    with pytest.raises(_lib.PgError) as ei:
+        lm.forward_logprobs(tok, np.arange(3), np.tile(np.array([3, 9], dtype=np.int32), (3, 1)), np.full((3, 2), 5, dtype=np.int32))
+    assert ei.value.code == _lib.PG_ERR_RANGE
+    ok = models.ESM1b(state_dict=_auto_setup()[1], config=cfg, precision="fp16").model.to("cuda:0")       # ordinary weights: no error
+    assert np.isfinite(ok.forward_logits(tok)).all()
