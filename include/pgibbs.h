@@ -278,6 +278,10 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
  * of 64 above 256); variant 1 =
  * lockstep kernel, 2 = ping-pong kernel; epi: 0 bf16 out, 1 bf16+gelu, 2 fp32 residual, 3 fp32, 4 fp32+gelu */
 int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int iters, double* avg_ms);
+/* round-5 ablation: QKV projection + attention of B sequences of T in {32, 64, 128, 256} tokens as ONE launch (the fused
+ * projection-attention kernel of the MSA column block, one head per 256 x 192 tile) against the two launches of the ESM-1b path;
+ * ms[0] fused, ms[1] projection, ms[2] attention (HIP events, `iters` launches each); max_diff = max |fused - unfused| context */
+int pg_dbg_qkv_attention_bench(int device, int B, int T, int H, int iters, double* ms, double* max_diff);
 /* y = LayerNorm(x[M][d]) * gamma + beta */
 int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d,
                      float eps);

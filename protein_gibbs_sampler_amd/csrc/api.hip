@@ -637,6 +637,81 @@ int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int
   return PG_OK;
 }
 
+// round 5 ablation ("QKV projection fused with attention for ESM-1b"): the fused kernel that exists --
+// gemm_colattn_kernel<16> with one "column" per chain IS projection + attention of whole sequences of T = 256 tokens, one head per
+// 256 x 192 tile, the fusion's best case (16 query blocks on 16 waves, no 17th block, no padded rows) -- against the two launches it
+// would replace (QKV projection with 256 x 256 tiles, attention_kernel) on the same operands.  ms[0] fused, ms[1] projection,
+// ms[2] attention; max_diff = max |ctx fused - ctx unfused| (0: the paths are bit-identical).
+int pg_dbg_qkv_attention_bench(int device, int B, int T, int H, int iters, double* ms, double* max_diff) {
+  if (!ms || B < 1 || H < 1 || iters < 1 || !(T == 32 || T == 64 || T == 128 || T == 256))
+    return fail(PG_ERR_INVALID, "pg_dbg_qkv_attention_bench: T must be 32, 64, 128 or 256");
+  DeviceGuard g(-1);
+  int rc = dbg_device(device);
+  if (rc) return rc;
+  const int d = H * 64;
+  const int64_t M = (int64_t)B * T, Mp = round_up64(M, kRowPad);
+  Tmp t;
+  float* f = (float*)t.get((size_t)Mp * d * 4);
+  bf16_t* bx = (bf16_t*)t.get((size_t)Mp * d * 2);
+  bf16_t* bw = (bf16_t*)t.get((size_t)3 * d * d * 2);
+  bf16_t* bwh = (bf16_t*)t.get((size_t)3 * d * d * 2);
+  float* db = (float*)t.get((size_t)3 * d * 4);
+  float* dbh = (float*)t.get((size_t)3 * d * 4);
+  bf16_t* qkv = (bf16_t*)t.get((size_t)Mp * 3 * d * 2);
+  bf16_t* c1 = (bf16_t*)t.get((size_t)Mp * d * 2);
+  bf16_t* c2 = (bf16_t*)t.get((size_t)Mp * d * 2);
+  if (!f || !bx || !bw || !bwh || !db || !dbh || !qkv || !c1 || !c2) return fail(PG_ERR_HIP, "hipMalloc failed");
+  std::vector<float> h((size_t)std::max<int64_t>(Mp, 3 * d) * d);
+  uint32_t st = 777u;
+  for (auto& v : h) { st = st * 1664525u + 1013904223u; v = ((st >> 8) * (1.0f / 8388608.0f) - 1.0f); }
+  PG_HIP(hipMemcpy(f, h.data(), (size_t)Mp * d * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, f, bx, Mp * d, 1.f))) return rc;
+  PG_HIP(hipMemcpy(f, h.data(), (size_t)3 * d * d * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, f, bw, (int64_t)3 * d * d, 0.03f))) return rc;
+  PG_HIP(hipMemcpy(db, h.data(), (size_t)3 * d * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_headmajor_qkv(nullptr, bw, db, bwh, dbh, H, d))) return rc;
+  PG_HIP(hipMemset(c1, 0, (size_t)Mp * d * 2));
+  PG_HIP(hipMemset(c2, 0, (size_t)Mp * d * 2));
+  hipEvent_t ev[2];
+  PG_HIP(hipEventCreate(&ev[0]));
+  PG_HIP(hipEventCreate(&ev[1]));
+  auto fused = [&] { return launch_gemm_colattn(nullptr, bx, bwh, dbh, c1, B, T, 1, H, d, d); };
+  auto proj = [&] { return launch_gemm_bf16(nullptr, bx, bw, db, qkv, (int)Mp, 3 * d, d, d, d, 3 * d, EPI_BF16); };
+  auto attn = [&] { return launch_attention_bf16(nullptr, qkv, c2, B, T, H, 3 * d, d, d, 2 * d); };
+  auto time_it = [&](auto&& fn, double* out) -> int {
+    int r;
+    for (int i = 0; i < 2; ++i)
+      if ((r = fn())) return r;
+    PG_HIP(hipEventRecord(ev[0], nullptr));
+    for (int i = 0; i < iters; ++i)
+      if ((r = fn())) return r;
+    PG_HIP(hipEventRecord(ev[1], nullptr));
+    PG_HIP(hipEventSynchronize(ev[1]));
+    float e = 0;
+    PG_HIP(hipEventElapsedTime(&e, ev[0], ev[1]));
+    *out = e / iters;
+    return PG_OK;
+  };
+  if ((rc = time_it(fused, ms + 0)) || (rc = time_it(proj, ms + 1)) || (rc = time_it(attn, ms + 2))) return rc;
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  if (max_diff) {
+    std::vector<uint16_t> a((size_t)M * d), b((size_t)M * d);
+    PG_HIP(hipMemcpy(a.data(), c1, a.size() * 2, hipMemcpyDeviceToHost));
+    PG_HIP(hipMemcpy(b.data(), c2, b.size() * 2, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+      uint32_t ua = (uint32_t)a[i] << 16, ub = (uint32_t)b[i] << 16;
+      float fa, fb;
+      memcpy(&fa, &ua, 4);
+      memcpy(&fb, &ub, 4);
+      worst = std::max(worst, (double)fabsf(fa - fb));
+    }
+    *max_diff = worst;
+  }
+  return PG_OK;
+}
+
 int pg_dbg_layernorm(int device, const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps) {
   if (!x || !gamma || !beta || !y || M < 1 || d < 4) return fail(PG_ERR_INVALID, "pg_dbg_layernorm: bad argument");
   DeviceGuard g(-1);
