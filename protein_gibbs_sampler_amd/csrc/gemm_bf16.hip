@@ -373,11 +373,13 @@ __device__ __forceinline__ void epilogue_192_resid(f32x4 (&acc)[4][6], char* sme
 // XJ = 16-row blocks of token rows per wave: 8 = the 256 x 256 tile; 6 = a 192 x 256 tile (residual epilogue only), chosen by
 // launch_gemm_big when 256-row tiles would leave a third of the CUs idle (165 tiles of a 32-chain shard's out-projection / fc2 on
 // 256 CUs: 220 tiles of three quarters the work instead).  Same k order per accumulator: a row's bits do not depend on the tile.
+constexpr int RS_ROUNDS = 1024;                   // rounds per XCD the pacing words cover (beyond: no pacing)
+constexpr unsigned long long RS_LIMIT = 4000;     // give up after 40 us of waiting (s_memrealtime ticks of 10 ns)
 template <int EPI, int ABL = 0, int GM = 4, int XJ = 8>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                           const float* __restrict__ bias, void* __restrict__ out, int K,
                                                           int ldx, int ldw, int ldo, int tiles_n, int n_tiles, int n_tail,
-                                                          int tail_m0) {
+                                                          int tail_m0, unsigned* rsync) {
   constexpr int HALF_BYTES = 512 * 64;            // one half-buffer: (256 + 256) rows x 64 B
   __shared__ __attribute__((aligned(16))) char smem[4 * HALF_BYTES];
   // the first n_tail workgroups: 64 x 64 tiles of the rows beyond the last full round of 256 x 256 tiles (gemm_epilogue.h)
@@ -403,6 +405,40 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   constexpr int NPX = XJ / 2;                     // 16-row DMA pieces per X-staging wave and half-step (W-staging waves: 4)
 
   int bid = n_tail > 0 ? blockIdx.x - n_tail : blockIdx.x;
+  // Round pacing (round 5; rsync != nullptr: deep-K residual GEMMs, fc2).  Workgroup b runs on XCD b % 8 and an XCD's 32 CUs take
+  // its workgroups in order, so workgroups 32r .. 32r+31 of an XCD are its "round" r: the GM x n rectangle of tiles that is meant to
+  // walk K together and share X / W k-slices through the XCD's 4 MB L2.  Only the first round does by itself -- afterwards every
+  // CU starts its next tile whenever it finishes, the rectangle's tiles drift apart by more K-steps than the L2 holds (352 KB per
+  // step, 80 steps at K = 5120) and each re-fetches its slices through the fabric: fc2 read 3.3 GB per launch against 1.2 GB for
+  // walking in step, and a lone round of 255 tiles -- launch, fill and drain included -- took 150 us where a steady-state round
+  // took 157 (profiles/r05_lockstep_rounds.txt).  With PGIBBS_GEMM_RSYNC=1 the workgroups of a round wait for each other before their
+  // first DMA (an ablation: it removes 40 % of the reads and does not pay, see round_sync_words()).  This
+  // is a scheduling hint, not a dependency: after RS_LIMIT the wait gives up (CUs taken by another process, a CU mask) and switches
+  // the pacing off for good; results cannot depend on it.
+  if (rsync && ABL == 0) {
+    if (threadIdx.x == 0 && __hip_atomic_load(rsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      const int xcd = bid & 7, q = bid >> 3, round = q >> 5;
+      const int per_xcd = (n_tiles >> 3) + (xcd < (n_tiles & 7) ? 1 : 0);
+      const unsigned size = (unsigned)((per_xcd - round * 32) < 32 ? (per_xcd - round * 32) : 32);
+      if (round < RS_ROUNDS && round > 0) {         // round 0 starts together anyway
+        unsigned* a = rsync + 16 + ((xcd * RS_ROUNDS + round) << 1);
+        __hip_atomic_fetch_add(a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool gave_up = false;
+        while (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < size) {
+          __builtin_amdgcn_s_sleep(8);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > RS_LIMIT) { gave_up = true; break; }
+        }
+        if (gave_up) __hip_atomic_store(rsync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // re-arm for the next launch: whoever leaves last clears both words (nobody is waiting on them any more)
+        if (__hip_atomic_fetch_add(a + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == size - 1u) {
+          __hip_atomic_store(a, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
   if (ABL == 18 && (bid & 7) != 0) return;        // timing experiment: only the workgroups of XCD 0 run (1/8 of the tiles)
   if (ABL == 19 && (bid & 7) > 1) return;         // ... XCDs 0 and 1
   {
@@ -560,14 +596,43 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 // epilogue takes < 2 us against 6 us per tile when all 256 CUs store together.  The vendor BLAS runs the same four shapes
 // without any epilogue at 1245-1273 TFLOP/s.
 // M rows of 256 x 256 tiles (M may be 0) + tail_rows rows of 64 x 64 tail tiles starting at row M, one grid
+// the pacing words of the current device (gemm_bf16_pp_kernel: "round pacing"): [0] = switched off by a timeout, [16 + 2 i] /
+// [17 + 2 i] = arrivals / departures of (XCD, round) i; zeroed once, re-armed by the kernel itself.  nullptr: no pacing here
+// (PGIBBS_GEMM_RSYNC=0, a device that is not 8 XCDs x 32 CUs, allocation failure).
+static unsigned* round_sync_words() {
+  static unsigned* words[64];
+  static bool tried[64];
+  // OFF by default: measured round 5 (profiles/r05_fc2_round_pacing.txt) -- pacing cuts fc2's fabric reads from 3.67 to 2.2 GB per
+  // launch (FETCH_SIZE) and the launch gets 1 % SLOWER (756 -> 763 us; ESM-MSA-1b's fc2 +3 %): the re-fetches are served by the
+  // Infinity Cache at no cost in time, while waiting for the slowest CU of a round is not free.  Kept as the ablation switch.
+  static const int on = [] { const char* e = getenv("PGIBBS_GEMM_RSYNC"); return e ? atoi(e) : 0; }();
+  int dev = 0;
+  if (!on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!tried[dev]) {
+    tried[dev] = true;
+    hipDeviceProp_t p;
+    void* w = nullptr;
+    const size_t bytes = (size_t)(16 + 2 * 8 * RS_ROUNDS) * 4;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount == 256 && hipMalloc(&w, bytes) == hipSuccess) {
+      if (hipMemset(w, 0, bytes) == hipSuccess) words[dev] = (unsigned*)w;
+    }
+  }
+  return words[dev];
+}
+
 static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
                      int ldx, int ldw, int ldo, int epi, int abl = 0, int tail_rows = 0, int tile_rows = 256) {
   const int tiles_m = M / tile_rows, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
   static const int tail_last = [] { const char* e = getenv("PGIBBS_GEMM_TAIL_LAST"); return e ? atoi(e) : 0; }();
+  static const int rsync_k = [] { const char* e = getenv("PGIBBS_GEMM_RSYNC_K"); return e ? atoi(e) : 4096; }();
   const int n_tail_abs = (tail_rows / 64) * (N / 64), tail_m0 = M;
-  const int n_tail = tail_last ? -n_tail_abs : n_tail_abs;
+  // round pacing: deep-K residual GEMMs of more than two rounds of 256-row tiles (fc2 of a big batch); the tail tiles then ride
+  // BEHIND the big ones (in front they would hold the first round's CUs back, and with them everybody who waits for that round)
+  unsigned* rsync = (epi == EPI_F32_RESID && !abl && tile_rows == 256 && K >= rsync_k && n_tiles > 2 * 256 && n_tail_abs % 8 == 0)
+                        ? round_sync_words() : nullptr;
+  const int n_tail = (tail_last || rsync) ? -n_tail_abs : n_tail_abs;
   dim3 grid(n_tiles + n_tail_abs), block(512);
-#define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0
+#define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, rsync
   if (abl) {   // ablations: EPI_BF16 only
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, PG_PP_ARGS);
     if (abl == 2) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 2>), grid, block, 0, s, PG_PP_ARGS);

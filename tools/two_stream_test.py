@@ -11,12 +11,13 @@ cfg = dict(weights.ESM1B_CONFIG)
 sd = weights.synthetic_state_dict(cfg, seed=0)
 dev = torch.device("cuda", 0)
 L_ = _lib.lib()
-B_total, L, P, K = 256, 256, 25, int(os.environ.get("STEPS", "6"))
+B_total, L, P, K = int(os.environ.get("CHAINS", "256")), 256, 25, int(os.environ.get("STEPS", "6"))
+JOB = int(os.environ.get("JOB_ITEMS", "0"))       # > 0: every engine is told it runs a shard of a JOB-chain job (pg_engine_set_job_items)
 T = L + 2
 valid_idx = list(range(4, 24))
 rng = np.random.default_rng(1234)
 tok_all = np.concatenate([np.zeros((B_total, 1), np.int64), np.asarray(valid_idx)[rng.integers(0, 20, (B_total, L))], np.full((B_total, 1), 2)], axis=1).astype(np.int32)
-for S in (1, 2, 4):
+for S in tuple(int(x) for x in os.environ.get("SPLITS", "1,2,4").split(",")):
     B = B_total // S
     engines, streams, toks, params, idxs = [], [], [], [], []
     for s_ in range(S):
@@ -25,6 +26,8 @@ for S in (1, 2, 4):
             lm = models.ESM1b(state_dict=sd, config=cfg).model.to("cuda:0")
         st = torch.cuda.Stream(dev)
         _lib.check(L_.pg_engine_set_stream(lm.handle, ctypes.c_void_p(st.cuda_stream)))
+        if JOB:
+            lm.set_job_items(JOB)
         engines.append(lm); streams.append(st)
         toks.append(torch.from_numpy(tok_all[s_ * B:(s_ + 1) * B]).to(dev).contiguous())
         params.append(_lib.make_sample_params(True, cfg["mask_idx"], 0, float("inf"), 1.0, valid_idx, rng_seed=0, rng_stream=0, row_id_base=s_ * B))
