@@ -249,6 +249,17 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
     __syncthreads();
     A::template stage<BIASKV>(base + (size_t)k0 * ld_qkv + k_off, ld_qkv, T - k0, Kh, Kl, tid, bk);
     A::template stage<BIASKV>(base + (size_t)k0 * ld_qkv + v_off, ld_qkv, T - k0, Vh, Vl, tid, bv);
+    // the tile's <pad> flags once per tile and wave, as wave-uniform bit masks (read per key, per query block and per
+    // tile inside the score loop they were the pattern that made the ragged bf16 attention 5x slower before its flags were staged;
+    // here the four fp32 tiles already fill the LDS two workgroups per CU may hold, so the flags live in scalar registers)
+    unsigned long long pm[(tpad + 63) / 64];
+    if (PADMASK) {
+#pragma unroll
+      for (int w = 0; w < (tpad + 63) / 64; ++w) {
+        const int key = w * 64 + lane;
+        pm[w] = __ballot(key < tpad && k0 + key < T && key_tok[row0 + (size_t)(k0 + key) * sl.row_step] == pad_idx);
+      }
+    }
     __syncthreads();
     const int tl = Tk - k0 - fq * 4;             // key k0 + kb*16 + fq*4 + r is padding iff kb*16 + r >= tl
 #pragma unroll
@@ -268,15 +279,14 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(
           if (kb * 16 + r >= tl) st[kb][r] = -3.0e38f;
       if (PADMASK) {      // <pad> keys of a ragged batch: token of key t at key_tok[row0 + t * row_step]; -inf for chains, fair-esm's
                           // finite -10000 for the MSA Transformer's column attention (attention.hip)
-        const int32_t* kt = key_tok + row0 + (size_t)k0 * sl.row_step;
         const float fill = sl.row_step == 1 ? -3.0e38f : -10000.0f;
 #pragma unroll
-        for (int kb = 0; kb < MAXKB; ++kb)
+        for (int kb = 0; kb < MAXKB; ++kb) {
+          const uint32_t f4 = (uint32_t)(pm[kb >> 2] >> ((kb & 3) * 16 + fq * 4)) & 0xfu;      // keys kb*16 + fq*4 .. +3 of the tile
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kb * 16 + fq * 4 + r;
-            if (k0 + key < T && kt[(size_t)key * sl.row_step] == pad_idx) st[kb][r] = fill;
-          }
+          for (int r = 0; r < 4; ++r)
+            if ((f4 >> r) & 1u) st[kb][r] = fill;
+        }
       }
       A::softmax_pv(st, o[j], m[j], l[j], Vh, Vl, fr, fq);
     }
@@ -632,7 +642,7 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
     // 20.5, 3 x 128 = 384 keys 25.7); ties go to the taller tile.  PGIBBS_ATTN_F32_KB = 6 / 8 / 10 forces one.
     int kb5 = 10;
     {
-      const int Tk = T;                                // plain form only (no bias key)
+      const int Tk = T + (bias_kv ? 1 : 0);            // every form: plain, <pad> mask, ESM-1's bias key (round 5)
       long best = ((long)Tk + 159) / 160 * 160;
       for (int k : {8, 6}) {
         const long padded = ((long)Tk + 16 * k - 1) / (16 * k) * (16 * k);
@@ -655,8 +665,8 @@ int launch_attention_f32(hipStream_t s, const float* qkv, bf16_t* ctx, int split
     else if (nqb == 1) PG_ATT_SPLIT(10, 1);
     else if (nqb == 2) PG_ATT_SPLIT(10, 2);
     else if (nqb == 3) PG_ATT_SPLIT(10, 3);
-    else if (kb5 == 6 && !bias_kv && !key_tok) hipLaunchKernelGGL((attention_split_kernel<6, 5, false, false>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx, bias_kv);
-    else if (kb5 == 8 && !bias_kv && !key_tok) hipLaunchKernelGGL((attention_split_kernel<8, 5, false, false>), grid, dim3(256), 0, s, qkv, ctx, split_d, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, n_qchunk, key_tok, pad_idx, bias_kv);
+    else if (kb5 == 6) PG_ATT_SPLIT(6, 5);
+    else if (kb5 == 8) PG_ATT_SPLIT(8, 5);
     else PG_ATT_SPLIT(10, 5);
 #undef PG_ATT_SPLIT
   }
