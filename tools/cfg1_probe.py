@@ -8,7 +8,7 @@ from protein_gibbs_sampler_amd import _lib, esm_sampler, models, weights
 cfg = dict(weights.ESM1B_CONFIG)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    s = esm_sampler.ESM_sampler(models.ESM1b(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg), device="gpu")
+    s = esm_sampler.ESM_sampler(models.ESM1b(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg, precision=os.environ.get("PGIBBS_TOOL_PRECISION", "bf16")), device="gpu")
 lm = s.model.model
 L = _lib.lib()
 seed = "MEPAATGQEAEECAHSGRGEAWEEV"

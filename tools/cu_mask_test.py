@@ -55,7 +55,7 @@ def run(kind):
     for s_ in range(S):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            lm = models.ESM1b(state_dict=sd, config=cfg).model.to("cuda:0")
+            lm = models.ESM1b(state_dict=sd, config=cfg, precision=os.environ.get("PGIBBS_TOOL_PRECISION", "bf16")).model.to("cuda:0")
         st = ctypes.c_void_p()
         if mk is not None:
             rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(mk[s_]), mk[s_])

@@ -17,7 +17,7 @@ P_ARG = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 cfg = dict(weights.ESM1B_CONFIG)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    wrapper = models.ESM1b(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg)
+    wrapper = models.ESM1b(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg, precision=os.environ.get("PGIBBS_TOOL_PRECISION", "bf16"))
 lm = wrapper.model.to("cuda:0")
 valid = sorted(wrapper.alphabet.get_idx(t) for t in "ACDEFGHIKLMNPQRSTVWY")
 B, L, P = B_ARG, 256, P_ARG

@@ -17,7 +17,7 @@ C = L + 1
 cfg = dict(weights.MSA1B_CONFIG)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    wrapper = models.ESM_MSA1(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg)
+    wrapper = models.ESM_MSA1(state_dict=weights.synthetic_state_dict(cfg, seed=0), config=cfg, precision=os.environ.get("PGIBBS_TOOL_PRECISION", "bf16"))
 lm = wrapper.model.to("cuda:0")
 valid = sorted(wrapper.alphabet.get_idx(t) for t in "-ACDEFGHIKLMNPQRSTVWY")
 rng = np.random.default_rng(1234)

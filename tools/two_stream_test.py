@@ -23,7 +23,7 @@ for S in tuple(int(x) for x in os.environ.get("SPLITS", "1,2,4").split(",")):
     for s_ in range(S):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            lm = models.ESM1b(state_dict=sd, config=cfg).model.to("cuda:0")
+            lm = models.ESM1b(state_dict=sd, config=cfg, precision=os.environ.get("PGIBBS_TOOL_PRECISION", "bf16")).model.to("cuda:0")
         st = torch.cuda.Stream(dev)
         _lib.check(L_.pg_engine_set_stream(lm.handle, ctypes.c_void_p(st.cuda_stream)))
         if JOB:
