@@ -10,6 +10,8 @@
 // Layout rule: one 64-lane wave per token row; a row of d fp32 is read as float4 per lane
 // (16 B x 64 lanes = 1 KiB coalesced per instruction); mean/variance by wave shuffle reductions;
 // nothing goes through LDS.
+#include <stdlib.h>
+
 #include "kernels.h"
 #include "ln_row.h"
 
@@ -102,6 +104,46 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const float* __rest
     if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
   ln_inplace(v, nch4, lane, d, eps, gamma, beta);
   store_row_bf16(h + (size_t)row * d * (split3 ? 3 : 1), v, nch4, lane, split3, split3 != 2);       // split3 == 2: no duplicate hi block
+}
+
+// Mid-size batches (a 32 ... 128-chain shard of a multi-GPU job: 8 k ... 33 k token rows): with one row per wave the grid is 1.03 ...
+// 4 "rounds" of what the chip holds at once (8 workgroups of 4 waves per CU), and the last, nearly empty round costs a whole
+// row latency -- 14.9 us for 8448 rows where an eighth of the full-size launch is 10.4 (profiles/r05_shard_timeline_32chains.txt).
+// Here the grid is exactly one resident round and every wave walks its rows (row, row + waves, ...) with the NEXT row's loads issued
+// before the current row is normalised.  Same per-row arithmetic (ln_inplace, store_row_bf16): same bits.
+// (the row width is a template parameter: with it the chunks a lane does not hold leave the register file -- 2 x 5 float4 at
+// d = 1280 instead of 2 x 8 -- and eight workgroups per CU stay resident, as for the plain kernel)
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_bf16_stride_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, bf16_t* __restrict__ h,
+                                                                   int split3, int64_t M, float eps) {
+  constexpr int d = D, nch4 = D >> 2;
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float4 v[kMaxCh], vn[kMaxCh];
+  {
+    const float4* x4 = (const float4*)(x + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < kMaxCh; ++i)
+      if (lane + 64 * i < nch4) v[i] = x4[lane + 64 * i];
+  }
+  for (;;) {
+    const int64_t next = row + stride;
+    if (next < M) {                                            // wave-uniform
+      const float4* x4 = (const float4*)(x + (size_t)next * d);
+#pragma unroll
+      for (int i = 0; i < kMaxCh; ++i)
+        if (lane + 64 * i < nch4) vn[i] = x4[lane + 64 * i];
+    }
+    ln_inplace(v, nch4, lane, d, eps, gamma, beta);
+    store_row_bf16(h + (size_t)row * d * (split3 ? 3 : 1), v, nch4, lane, split3, split3 != 2);
+    if (next >= M) break;
+#pragma unroll
+    for (int i = 0; i < kMaxCh; ++i) v[i] = vn[i];
+    row = next;
+  }
 }
 
 // The same with the output rows in COLUMN-MAJOR token order: token row (b*R + r)*C + c -> operand row (b*C + c)*R + r, so that a
@@ -352,6 +394,34 @@ int launch_layernorm_bf16(hipStream_t s, const float* x, const float* gamma, con
     hipLaunchKernelGGL(layernorm_bf16_colmajor_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, M, d, eps, colmajor_R, colmajor_C);
     PG_HIP(hipGetLastError());
     return 0;
+  }
+  {
+    // one resident round of workgroups walking their rows when the plain grid would be 1 ... 4 rounds (layernorm_bf16_stride_kernel)
+    static const int on = [] { const char* e = getenv("PGIBBS_LN_STRIDE"); return e ? atoi(e) : 1; }();
+    static const int n_cu = [] {
+      hipDeviceProp_t p; int dv = 0; (void)hipGetDevice(&dv);
+      return hipGetDeviceProperties(&p, dv) == hipSuccess ? p.multiProcessorCount : 256;
+    }();
+    const unsigned g1 = rows_grid(M);
+    if (on && (d == 1280 || d == 768) && g1 > (unsigned)n_cu * 8 && g1 <= (unsigned)n_cu * 32) {
+      // the grid = what is resident at once (occupancy of this very kernel x CUs, asked once per width)
+      static int occ[2] = {0, 0};
+      int& oc = occ[d == 768];
+      if (oc == 0) {
+        int v = 0;
+        const hipError_t e = d == 1280 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, layernorm_bf16_stride_kernel<1280>, 256, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, layernorm_bf16_stride_kernel<768>, 256, 0);
+        oc = (e == hipSuccess && v > 0) ? v : -1;
+      }
+      if (oc > 0 && g1 > (unsigned)(n_cu * oc)) {
+        const dim3 grid((unsigned)(n_cu * oc));
+        const int sp = split3 ? (split3_dup ? 1 : 2) : 0;
+        if (d == 1280) hipLaunchKernelGGL(layernorm_bf16_stride_kernel<1280>, grid, dim3(256), 0, s, x, gamma, beta, h, sp, M, eps);
+        else hipLaunchKernelGGL(layernorm_bf16_stride_kernel<768>, grid, dim3(256), 0, s, x, gamma, beta, h, sp, M, eps);
+        PG_HIP(hipGetLastError());
+        return 0;
+      }
+    }
   }
   hipLaunchKernelGGL(layernorm_bf16_kernel, dim3(rows_grid(M)), dim3(256), 0, s, x, gamma, beta, h, split3 ? (split3_dup ? 1 : 2) : 0, M, d, eps);
   PG_HIP(hipGetLastError());

@@ -86,6 +86,19 @@ class NativeMaskedLM:
                 inout[...] = keep
             return fn()
 
+    def _check_fp16_msa_shape(self, tok):
+        """Explicit precision="fp16" on the MSA engine: the shapes its fp16 kernels lack are refused BEFORE any work is queued
+        (they used to surface as PG_ERR_UNSUPPORTED in the middle of a pgen_msa run).  precision="auto" goes on and
+        falls back to bf16 inside _guarded."""
+        if self.is_msa and self.precision == _lib.PG_PREC_F16 and not self.auto:
+            if tok.shape[-1] > 576:
+                raise ValueError("precision='fp16': alignments wider than 576 token columns (<cls> + 575 residues) take the row "
+                                 "attention's scores-through-scratch form, which exists for bf16 operands only -- use "
+                                 "precision='auto', 'bf16' or 'fp32'")
+            if (tok == self.cfg["pad_idx"]).any():
+                raise ValueError("precision='fp16': batches that hold <pad> (ragged MSA lists) are supported with bf16 operands "
+                                 "only -- use precision='auto', 'bf16' or 'fp32'")
+
     def _probe(self):
         """One small forward right after the engine exists: a checkpoint whose activations leave the fp16 range is moved to bf16
         here, before any user call (PGIBBS_F16_PROBE=0 skips it)."""
@@ -178,6 +191,7 @@ class NativeMaskedLM:
         L = _lib.lib()
         if self.is_msa:
             B, R, C = tok.shape
+            self._check_fp16_msa_shape(tok)
             out = np.empty((B, R, C, V), dtype=np.float32)
             self._guarded(lambda: _lib.check(L.pg_msa_forward_logits(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(out))))
         else:
@@ -197,6 +211,7 @@ class NativeMaskedLM:
         L = _lib.lib()
         if self.is_msa:
             B, R, C = tok.shape
+            self._check_fp16_msa_shape(tok)
             self._guarded(lambda: _lib.check(L.pg_msa_forward_logprobs(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(row_of), _lib.ptr(idx),
                                                                        _lib.ptr(targets), n_sel, P, _lib.ptr(out))))
         else:
@@ -218,6 +233,7 @@ class NativeMaskedLM:
         L = _lib.lib()
         if self.is_msa:
             B, R, C = tok.shape
+            self._check_fp16_msa_shape(tok)
             self._guarded(lambda: _lib.check(L.pg_msa_gibbs_run(self.handle, _lib.ptr(tok), B, R, C, _lib.ptr(idx), n_iters, P, ctypes.byref(params),
                                                                 _lib.ptr(lg) if want_logits else None, _lib.ptr(st) if want_tokens else None)), tok)
         else:
@@ -243,6 +259,7 @@ class NativeMaskedLM:
         tok = tokens
         assert tok.dtype == np.int32 and tok.flags.c_contiguous and tok.ndim == 3
         B, R, C = tok.shape
+        self._check_fp16_msa_shape(tok)
         idx = np.ascontiguousarray(step_idx, dtype=np.int32)
         flags = np.ascontiguousarray(step_sample, dtype=np.int32)
         n_steps, Bi, P = idx.shape

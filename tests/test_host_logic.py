@@ -424,3 +424,22 @@ def test_checkpoint_without_embedding_layernorm_is_named(tmp_path):
     _args_pt(path, sd, cfg, "roberta_large")
     with pytest.raises(ValueError, match="without emb_layer_norm_before"):
         weights.load_fair_esm_checkpoint(str(path), cfg)
+
+
+def test_explicit_fp16_refuses_unsupported_msa_shapes_up_front():
+    """precision='fp16' on the MSA engine used to fail with PG_ERR_UNSUPPORTED in the middle of a run for alignments wider
+    than 576 columns or batches that hold <pad>; the wrapper refuses them before any work is queued (no GPU needed to see it)."""
+    from protein_gibbs_sampler_amd import weights
+    from protein_gibbs_sampler_amd.engine import NativeMaskedLM
+    cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=128, n_layers=1, d_ffn=256, max_positions=700, max_msa_rows=8)
+    lm = NativeMaskedLM(cfg, {}, precision="fp16")
+    wide = np.full((1, 2, 600), 5, dtype=np.int32)
+    with pytest.raises(ValueError, match="wider than 576"):
+        lm.forward_logits(wide)
+    padded = np.full((1, 2, 20), 5, dtype=np.int32)
+    padded[0, 1, 7] = cfg["pad_idx"]
+    with pytest.raises(ValueError, match="<pad>"):
+        lm.gibbs_run(padded, np.zeros((1, 1, 2, 1), np.int32), None)
+    auto = NativeMaskedLM(cfg, {}, precision="auto")
+    with pytest.raises(RuntimeError, match="not resident"):          # auto goes on (and would fall back on the GPU): no shape refusal
+        auto.forward_logits(wide)
