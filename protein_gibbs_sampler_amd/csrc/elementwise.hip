@@ -460,7 +460,11 @@ int launch_lm_tail(hipStream_t s, const float* g, const float* gamma, const floa
                    const float* out_bias, float* logits, int64_t n, int d, int V, float eps) {
   if (V > 64) return fail(1, "lm_tail: vocab > 64 unsupported");
   if (n == 0) return 0;
-  if (n <= 128) {        // identical arithmetic per logit (same per-lane partial sums, same wave reduction): bit-equal results
+  // identical arithmetic per logit (same per-lane partial sums, same wave reduction): bit-equal results.  Up to 1024 rows (round 5;
+  // it was 128): a 32-chain shard's 800 sampled rows took 81 us on the row-per-wave kernel -- 200 workgroups, each wave walking the
+  // decoder rows in nine dependent trips -- PGIBBS_LM_TAIL_SMALL=n moves the switch
+  static const int small_max = [] { const char* e = getenv("PGIBBS_LM_TAIL_SMALL"); return e ? atoi(e) : 1024; }();
+  if (n <= small_max) {
     hipLaunchKernelGGL(lm_tail_small_kernel, dim3((unsigned)n), dim3(64 * ((V + 3) / 4)), 0, s, g, gamma, beta, embed, out_bias, logits,
                        d, V, eps);
     PG_HIP(hipGetLastError());
