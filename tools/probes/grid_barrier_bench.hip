@@ -180,6 +180,62 @@ __global__ __launch_bounds__(512) void phases_kernel(unsigned* sync, float* act,
   if (accum == 12345.678f) sink[blockIdx.x * 512 + tid] = accum;
 }
 
+// Form 7 (round 5): NO barrier -- the epoch travels inside the data (the "LL" protocol of the collective
+// libraries).  A phase's output is xkb KB of payload as 8-byte units (4 bytes of payload + 4 bytes of epoch, one single-copy-atomic
+// device-scope store each), spread over all workgroups; every workgroup then reads ALL units with device-scope 16-byte loads and
+// re-reads until every unit shows this phase's epoch.  Two buffers alternate by phase parity (a workgroup can only start writing
+// phase p + 2 after it has seen all of phase p + 1, which every other workgroup wrote after it had finished reading phase p).
+// The 40 KB of weights per workgroup are fetched first, as in work mode 2.  What it measures: one store-to-load propagation + the
+// polling traffic (G workgroups x 2 xkb KB per attempt) against the store-acknowledge + barrier + load of forms 4 / 5.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void ll_phases_kernel(unsigned* sync, v2u* act, const uint4* w, unsigned w_mask, float* sink, int n_phases,
+                                                        int xkb) {
+  const int G = gridDim.x, tid = threadIdx.x, b = blockIdx.x;
+  const int NU = xkb * 256;                          // units = payload floats
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)act, 0, 0x7fffffff, 0x00020000);
+  float accum = 0.f;
+  unsigned wpos = blockIdx.x * 2560u;
+  for (int p = 0; p < n_phases; ++p) {
+    uint4 wreg[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wreg[i] = w[(wpos + i * 512u + tid) & w_mask];
+    wpos += (unsigned)G * 2560u;
+    const unsigned epoch = (unsigned)(p + 1);
+    const int base = (p & 1) * NU;
+    for (int u = tid * G + b; u < NU; u += 512 * G) {
+      const v2u val = {__float_as_uint(accum + (float)p), epoch};
+      __builtin_amdgcn_raw_buffer_store_b64(val, rs, (base + u) * 8, 0, 16);          // sc1
+    }
+    // consume: thread t of every workgroup takes unit pairs t, t + 512, ...
+    const int n2 = NU / 2;
+    float got = 0.f;
+    const long long t0 = wall_clock64();
+    for (int q = tid; q < n2; q += 512 * 4) {
+      v4u v[4];
+      bool ok;
+      do {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int qq = q + i * 512;
+          v[i] = qq < n2 ? __builtin_amdgcn_raw_buffer_load_b128(rs, (base + 2 * qq) * 8, 0, 16) : (v4u){0u, epoch, 0u, epoch};
+        }
+        ok = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok = ok && v[i][1] == epoch && v[i][3] == epoch;
+        if (!ok && wall_clock64() - t0 > 5000000) { sync[1] = 1; ok = true; }
+      } while (!ok);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) got += __uint_as_float(v[i][0]) + __uint_as_float(v[i][2]);
+    }
+    accum += got * 1e-30f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) accum += (float)(wreg[i].x ^ wreg[i].y ^ wreg[i].z ^ wreg[i].w) * 1e-30f;
+    __syncthreads();                                 // the workgroup's phase ends when all of its waves have their inputs
+  }
+  if (accum == 12345.678f) sink[blockIdx.x * 512 + tid] = accum;
+}
+
 int main() {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -211,5 +267,23 @@ int main() {
   for (int bar = 0; bar < 7; ++bar) { run(bar, 0, 0, NCU); run(bar, 0, 0, NCU / 2); run(bar, 0, 0, 64); }
   for (int bar : {0, 2, 3}) { run(bar, 1, 69, NCU); run(bar, 1, 138, NCU); run(bar, 2, 69, NCU); run(bar, 2, 138, NCU); }
   for (int bar : {4, 5, 6}) { run(bar, 2, 69, NCU); run(bar, 2, 138, NCU); }
+  {
+    v2u* act2; CK(hipMalloc(&act2, 2 * 138 * 256 * 8 * 2));
+    for (int xkb : {8, 35, 69, 138}) for (int grid : {NCU, NCU / 2}) {
+      float best = 1e30f; unsigned herr[2] = {0, 0};
+      for (int rep = 0; rep < 4; ++rep) {
+        CK(hipMemset(sync, 0, 8192)); CK(hipMemset(act2, 0, 2 * 138 * 256 * 8 * 2));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(ll_phases_kernel, dim3(grid), dim3(512), 0, 0, sync, act2, w, w_mask, sink, NP, xkb);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+        CK(hipMemcpy(herr, sync, 8, hipMemcpyDeviceToHost));
+      }
+      printf("epoch-in-data (no barrier) work 2 grid %3d payload %3d KB (%3d KB of units): %6.2f us per phase%s\n", grid, xkb, 2 * xkb, best * 1e3f / NP,
+             herr[1] ? "  [TIMEOUT FLAG SET]" : "");
+      fflush(stdout);
+    }
+  }
   return 0;
 }
