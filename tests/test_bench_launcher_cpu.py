@@ -37,3 +37,25 @@ def test_bench_self_launches_and_shards_config3(n):
 def test_bench_weak_scaling_flag():
     out = _run("--gpus", "2", "--weak")
     assert out["scaling"] == "weak" and out["config"]["global_batch"] == 512
+
+
+def test_cpu_baseline_leg_and_traffic_file_selection():
+    """The two parts of the bench line VERDICT r04 found wrong, runnable without a GPU: (1) `roofline.traffic` comes from the newest
+    ESM-1b PMC file -- never from an ESM-MSA-1b one -- and carries the four per-layer GEMMs; (2) the CPU-baseline leg (BASELINE.md
+    section 3: chains x iterations in torch CPU ops at the fastest thread count, config 1 in full, the per-position loop) runs and
+    reports the fields the line promises -- here on ONE layer of the real widths and 2 chains, with no engine to check."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from protein_gibbs_sampler_amd import weights
+    total, per, src = bench.measured_gemm_traffic()
+    assert src and "_msa_" not in src and src.endswith("_hbm_traffic_pmc.json")
+    assert set(per) == {"gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2"} and 1.5e9 < total < 4e9
+    cfg = dict(weights.ESM1B_CONFIG)
+    cfg["n_layers"] = 1
+    sd = weights.synthetic_state_dict(cfg, seed=0, **bench.SYNTH_KW)
+    out = bench.cpu_baseline(cfg, sd, None, None, 256, 64, 6, list(range(4, 24)), None, chains=2, iters=2, check_chains=1)
+    assert out["kind"] == "port" and out["unit"] == "sampled positions/s" and out["value"] > 0
+    assert out["cores"] in [int(k) for k in out["thread_sweep_s_per_layer"]] and out["cores"] <= out["host_logical_cpus"]
+    assert "2 of 256 chains x 2 Gibbs iterations" in out["sample"]
+    assert out["logit_check"]["torch_baseline_vs_checker_max_abs"] < 1e-3
+    assert out["config1"]["cpu_ms_per_iter"] > 0 and out["reference_style_position_loop"]["us_per_position_one_core"] > 0
