@@ -91,3 +91,22 @@ def test_comm_entry_points_reject_bad_arguments_and_need_a_gpu():
     assert L.pg_gather_tokens(None, None, None, 0, 1, None, None) == _lib.PG_ERR_INVALID
     assert L.pg_comm_rank(None) == -1 and L.pg_comm_world(None) == 0
     L.pg_comm_destroy(None)
+
+
+def test_header_is_plain_c_and_the_c_client_fails_loudly_without_a_gpu(tmp_path):
+    """include/pgibbs.h must bind from C, not only from C++ / ctypes: examples/pgibbs_client.c (C99, -Wall -Werror) compiles and
+    links against the library with gcc; without a GPU it stops at pg_device_count() with a message and a non-zero status -- it
+    does not compute anything on the host."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("needs gcc and the ROCm runtime library")
+    lib_dir = os.path.join(ROOT, "protein_gibbs_sampler_amd", "lib")
+    exe = tmp_path / "client"
+    p = subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "pgibbs_client.c"), "-L", lib_dir, "-lpgibbs", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    if _lib.lib().pg_device_count() == 0:
+        r = subprocess.run([str(exe), str(tmp_path / "w.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 3 and "no MI355X" in r.stderr and not (tmp_path / "o.bin").exists()
