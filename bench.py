@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-strict", action="store_true", help="skip the strict-mode leg (N = 1)")
     ap.add_argument("--no-host-entry", action="store_true", help="skip the host-buffer entry-point leg (PCIe-inclusive rate; N = 1)")
     ap.add_argument("--no-msa", action="store_true", help="skip the ESM-MSA-1b legs (BASELINE configs 4 and 5; N = 1)")
+    ap.add_argument("--native-gather", action="store_true",
+                    help="after the timed region: repeat the final gather through the C ABI (pg_comm_* / pg_gather_tokens, RCCL opened by "
+                         "libpgibbs.so itself) and require the same tokens (`native_gather_equal`); RCCL backend only")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still create the torch.distributed process group (world_size 1) and run the final all-gather "
                          "through it, so that the RCCL path is executed on a single GPU")
@@ -428,6 +431,19 @@ def main():
                                     "steps": W + K, "includes": "H2D of tokens + position table, D2H of tokens (PCIe), one native call",
                                     "equals_device_pointer_job": bool((tok_h == final).all())}
         assert out["host_buffer_entry"]["equals_device_pointer_job"], "host-buffer entry point disagrees with the device-pointer one"
+
+    # ---- opt-in: the same collective through the C ABI (no torch in the data path), outside the timed region ----
+    if args.native_gather and dist is not None and backend == "nccl" and not dry:
+        comm = sharding.NativeComm(rank, world, dev.index)                 # the id travels over the existing process group
+        lm.synchronize()
+        nat = comm.gather_tokens(job.tok, counts)
+        torch.cuda.synchronize(dev)
+        same = bool((nat.cpu().numpy() == final).all())
+        comm.close()
+        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        out["native_gather_equal"] = bool(flag.item())
+        assert out["native_gather_equal"], "pg_gather_tokens disagrees with the torch.distributed gather"
 
     # ---- N > 1: the gathered tokens must equal the single-GPU result bit for bit (rank 0, outside the timed region) ----
     if not dry and dist is not None and not args.no_verify:

@@ -30,9 +30,10 @@ def test_rccl_world_size_one_collectives_and_run_sharded():
 
 def test_bench_single_gpu_through_rccl():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1",
-                        "--layers", "2", "--no-cpu-baseline", "--no-strict", "--no-msa", "--no-roofline"], capture_output=True,
+                        "--layers", "2", "--no-cpu-baseline", "--no-strict", "--no-msa", "--no-roofline", "--native-gather"], capture_output=True,
                        text=True, env=_env(), timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
     assert out["verified_vs_single_gpu"] is True and out["value"] > 0
+    assert out["native_gather_equal"] is True              # the C-ABI collective (pg_gather_tokens) returned the same tokens
