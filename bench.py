@@ -75,7 +75,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-msa", action="store_true", help="skip the ESM-MSA-1b legs (BASELINE configs 4 and 5; N = 1)")
     ap.add_argument("--native-gather", action="store_true",
                     help="after the timed region: repeat the final gather through the C ABI (pg_comm_* / pg_gather_tokens, RCCL opened by "
-                         "libpgibbs.so itself) and require the same tokens (`native_gather_equal`); RCCL backend only")
+                         "libpgibbs.so itself) and require the same tokens (`native_gather_equal`); RCCL backend only.  Since round 6 this "
+                         "is the DEFAULT whenever more than one rank runs on the nccl backend; the flag forces it at world size 1 too")
+    ap.add_argument("--no-native-gather", action="store_true", help="N > 1 on nccl: skip the C-ABI repeat of the gather")
+    ap.add_argument("--no-shard-proxy", action="store_true",
+                    help="N = 1: skip the shard_proxy leg (128 / 64 / 32 chains of the 256-chain job on this one GPU: what one GPU of "
+                         "BASELINE config 3 runs at 2 / 4 / 8 GPUs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: still create the torch.distributed process group (world_size 1) and run the final all-gather "
                          "through it, so that the RCCL path is executed on a single GPU")
@@ -140,6 +145,64 @@ def measured_gemm_traffic():
     return sum(v["launches"] * (v["read"] + v["write"]) for v in per.values()) / n, per, os.path.basename(paths[-1])
 
 
+def pmc_derived():
+    """north_star's evidence words -- matrix-pipe (MFMA) utilisation and L2 hit rate of the hot kernels -- derived from the newest
+    committed profiles/rNN_gemm_pmc_counters.txt (tools/pmc_bench.sh: three rocprofv3 --pmc passes per kernel; PMC cannot be read
+    from inside the timed process, so like roofline.traffic this is a committed measurement of the same kernels, with its file name):
+      mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (n_SIMD x GRBM_GUI_ACTIVE / n_XCD)   (busy matrix-pipe cycles per SIMD / kernel cycles)
+      l2_hit    = TCC_HIT / (TCC_HIT + TCC_MISS);   l2_read_latency_cycles = TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ"""
+    import ast
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc_counters.txt")))
+    if not paths:
+        return None
+    kern, cur = {}, None
+    for ln in open(paths[-1]):
+        ln = ln.strip()
+        if ln.startswith("== "):
+            cur = kern.setdefault(ln[3:].strip(), {})
+        elif ln.startswith("pass ") and cur is not None and "{" in ln:
+            try:
+                cur.update(ast.literal_eval(ln[ln.index("{"):ln.rindex("}") + 1]))
+            except (ValueError, SyntaxError):
+                pass
+    out = {"source": os.path.basename(paths[-1]), "kernels": {}}
+    for k, c in kern.items():
+        d = {}
+        if c.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            d["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+        if c.get("TCC_HIT") is not None and (c.get("TCC_HIT", 0) + c.get("TCC_MISS", 0)) > 0:
+            d["l2_hit"] = c["TCC_HIT"] / (c["TCC_HIT"] + c["TCC_MISS"])
+        if c.get("TCP_TCC_READ_REQ"):
+            d["l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY"] / c["TCP_TCC_READ_REQ"]
+        if c.get("SQ_WAVE_CYCLES"):
+            d["wave_cycles_waiting"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
+        out["kernels"][k] = d
+    return out
+
+
+def host_cpu_quota():
+    """What the host really grants this process: logical CPUs, the scheduler affinity mask, and the cgroup CPU quota (cgroup v2
+    cpu.max / v1 cfs_quota_us) in CPUs -- the MI355X boxes report 256 logical CPUs but a container may be capped far below."""
+    q = {"logical_cpus": os.cpu_count()}
+    try:
+        q["sched_affinity_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q["cgroup_cpu_max"] = "%s %s" % (a, b)
+        q["cgroup_quota_cpus"] = None if a == "max" else float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            a = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            b = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            q["cgroup_quota_cpus"] = None if a < 0 else a / b
+        except (OSError, ValueError):
+            q["cgroup_quota_cpus"] = "unknown"
+    return q
+
+
 def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, lm_f16=None, chains=8, iters=2, check_chains=2):
     """the reference's CPU path -- fair-esm fp32 under PyTorch, all host cores -- as this repo's torch-CPU
     restatement (oracle/esm_forward_torch.py; fair-esm itself is not installed and reference files never travel to the GPU box):
@@ -192,7 +255,7 @@ def cpu_baseline(cfg, sd, lm, lm_strict, B, L, P, valid_idx, gpu_cfg1, lm_f16=No
                      "reference path (full forward + LM head on every row + per-position torch draw loop), %d threads = the fastest count of a sweep on this host, "
                      "%.1f s (forward %.1f s, draw loop %.2f s); chains are independent, so the whole-batch figure is the same rate"
                      % (chains, B, iters, L, P, cores, t, t_fwd, t_loop),
-           "host_logical_cpus": n_cpu, "thread_sweep_s_per_layer": {str(k_): round(v_, 4) for k_, v_ in sweep.items()},
+           "host_logical_cpus": n_cpu, "host_cpu_quota": host_cpu_quota(), "thread_sweep_s_per_layer": {str(k_): round(v_, 4) for k_, v_ in sweep.items()},
            "seconds_per_iteration_scaled_to_%d_chains" % B: t / iters * B / chains,
            "forward_gflops_per_s": total_flops_per_iter(cfg, chains * (L + 2), L + 2, chains * (L + 2)) * iters / t_fwd / 1e9}
 
@@ -374,10 +437,14 @@ def main():
         gathered = sharding.gather_tokens(dist, src, counts)           # the one collective: final token buffers
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_elapsed = [elapsed]
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        # every rank's own clock around the same barrier-bracketed region: the MAX is the job's time, min / max show the skew
+        mine_t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        all_t = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(all_t, mine_t)
+        rank_elapsed = [float(t_.item()) for t_ in all_t]
+        elapsed = max(rank_elapsed)
     final = (gathered if gathered is not None else job.tok).cpu().numpy()
     assert final.shape == (B_total, T)
     if not dry:
@@ -399,7 +466,9 @@ def main():
                       "parallelism": "chains sharded %d-way (contiguous blocks), 1 %s all-gather at the end"
                                      % (world, "RCCL" if backend == "nccl" else "gloo"),
                       "n_layers": cfg["n_layers"]},
-           "ranks_seen": 1, "backend": backend if dist is not None else None}
+           "ranks_seen": 1, "backend": backend if dist is not None else None,
+           "per_rank_elapsed_s": {"min": min(rank_elapsed), "max": max(rank_elapsed), "ranks": rank_elapsed,
+                                  "chains_per_rank": counts}}
     if dist is not None:
         # counted, not assumed: every rank contributes a one to an all-reduce on the job's backend
         ones = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
@@ -433,17 +502,27 @@ def main():
         assert out["host_buffer_entry"]["equals_device_pointer_job"], "host-buffer entry point disagrees with the device-pointer one"
 
     # ---- opt-in: the same collective through the C ABI (no torch in the data path), outside the timed region ----
-    if args.native_gather and dist is not None and backend == "nccl" and not dry:
-        comm = sharding.NativeComm(rank, world, dev.index)                 # the id travels over the existing process group
-        lm.synchronize()
-        nat = comm.gather_tokens(job.tok, counts)
-        torch.cuda.synchronize(dev)
-        same = bool((nat.cpu().numpy() == final).all())
-        comm.close()
-        flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        out["native_gather_equal"] = bool(flag.item())
-        assert out["native_gather_equal"], "pg_gather_tokens disagrees with the torch.distributed gather"
+    want_native = args.native_gather or (world > 1 and not args.no_native_gather)
+    if want_native and dist is not None and backend == "nccl" and not dry:
+        # every rank first proves it can open RCCL through the library (pg_comm_unique_id needs nothing else); only if ALL can
+        # does anybody enter the collective ncclCommInitRank -- a rank that cannot must not leave the others waiting in it
+        probe = ctypes.create_string_buffer(_lib.PG_COMM_ID_BYTES)
+        can = torch.tensor([1 if L_.pg_comm_unique_id(probe) == 0 else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        if int(can.item()) == 1:
+            comm = sharding.NativeComm(rank, world, dev.index)             # the id travels over the existing process group
+            lm.synchronize()
+            nat = comm.gather_tokens(job.tok, counts)
+            torch.cuda.synchronize(dev)
+            same = bool((nat.cpu().numpy() == final).all())
+            comm.close()
+            flag = torch.tensor([1 if same else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            out["native_gather_equal"] = bool(flag.item())
+            assert out["native_gather_equal"], "pg_gather_tokens disagrees with the torch.distributed gather"
+        else:
+            out["native_gather_equal"] = None
+            out["native_gather_note"] = "librccl.so could not be opened by libpgibbs.so on some rank: " + (L_.pg_last_error() or b"").decode()
 
     # ---- N > 1: the gathered tokens must equal the single-GPU result bit for bit (rank 0, outside the timed region) ----
     if not dry and dist is not None and not args.no_verify:
@@ -536,9 +615,67 @@ def main():
                                "peak_note": "peak = dense bf16 MFMA rate at 2.4 GHz; under this load the shader clock measured inside "
                                             "the GEMM main loop is ~1.72 GHz (power limit: 2.29 GHz with all-zero operands), "
                                             "profiles/r02_gemm_clock_probe.txt"}
+            # north_star: "evidenced by rocprof HBM GB/s and MFMA utilisation".  (a) HBM-bound kernels of THIS run: bytes from the
+            # shapes / this run's HIP-event time.  LayerNorm: 2 per layer on all M rows (fp32 row in, 16-bit row out) but for the
+            # pruned last layer (one, on B*P rows); attention: q | k | v in, context out, one launch per layer.
+            nl_ = cfg["n_layers"]
+            ln_ms, ln_n = parts["layernorm"]
+            at_ms, at_n = parts["attention"]
+            ln_bytes = n_prof * (2 * (nl_ - 1) * Mr * d_ * (4 + el) + (B * P) * d_ * (4 + el))   # layer 0's LN1 is part of the embedding pass
+            at_bytes = n_prof * nl_ * (Mr * 3 * d_ * el + Mr * d_ * el)
+            hbm_peak = 8000.0
+            out["roofline"]["hbm_bound_kernels"] = {
+                "peak_GBps": hbm_peak, "achievable_GBps": 6300.0,
+                "layernorm_bf16_kernel": {"launches_per_iter": ln_n // n_prof, "algorithmic_MB_per_iter": ln_bytes / n_prof / 1e6,
+                                          "ms_per_iter": ln_ms / n_prof, "achieved_GBps": ln_bytes / (ln_ms * 1e-3) / 1e9 if ln_ms else None,
+                                          "frac_of_hbm_peak": ln_bytes / (ln_ms * 1e-3) / 1e9 / hbm_peak if ln_ms else None},
+                "attention_kernel": {"launches_per_iter": at_n // n_prof, "algorithmic_MB_per_iter": at_bytes / n_prof / 1e6,
+                                     "ms_per_iter": at_ms / n_prof, "achieved_GBps": at_bytes / (at_ms * 1e-3) / 1e9 if at_ms else None,
+                                     "frac_of_hbm_peak": at_bytes / (at_ms * 1e-3) / 1e9 / hbm_peak if at_ms else None,
+                                     "gflop_per_launch": 4.0 * T * d_ * Mr / 1e9,
+                                     "tflops": (4.0 * T * d_ * Mr * at_n) / (at_ms * 1e-3) / 1e12 if at_ms else None}}
+            # (b) PMC-derived matrix-pipe utilisation and L2 hit rate of the hot kernels from the committed counters file
+            pd = pmc_derived()
+            if pd:
+                kd = pd["kernels"]
+                fam = "gemm_bf16_w16_kernel" if dom in ("gemm_fc1", "gemm_qkv") else "gemm_bf16_pp_kernel"
+                out["roofline"]["mfma_util"] = kd.get(fam, {}).get("mfma_util")
+                out["roofline"]["l2_hit"] = kd.get(fam, {}).get("l2_hit")
+                out["roofline"]["pmc_derived"] = kd
+                out["roofline"]["pmc_note"] = ("mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs), l2_hit = TCC_HIT / "
+                                               "(TCC_HIT + TCC_MISS); separate rocprofv3 --pmc passes of tools/pmc_bench.sh over the same kernels at the "
+                                               "config-2 shapes, committed as profiles/%s (PMC cannot be read inside the timed process); the top-level "
+                                               "mfma_util / l2_hit are those of the dominant kernel's family (%s)" % (pd["source"], fam))
         if rank == 0:
             out["time_split_ms_per_iter"] = {c: parts[c][0] / n_prof for c in ("gemm", "attention", "layernorm", "embed", "head", "sample")}
             out["time_split_ms_per_iter"]["gemm_by_projection"] = {c: parts[c][0] / n_prof for c in ("gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2", "gemm_other")}
+
+    # ---- N = 1: shard_proxy -- what ONE GPU of BASELINE config 3 runs at 2 / 4 / 8 GPUs, measured on this GPU ----------------
+    # The first 128 / 64 / 32 chains of the SAME 256-chain job (engine told `set_job_items(256)`: the kernel choices of the whole job,
+    # so the shard's tokens are bit-identical with the single-GPU run's -- tests/test_gpu_fullsize.py), ms per Gibbs iteration,
+    # efficiency against 1/N of this run's full-batch step, and the whole-node rate N such GPUs would deliver (the final 33-KB
+    # all-gather is not in it: microseconds once per job).  Chains are independent in the reference (esm_sampler.py:223-234).
+    if rank == 0 and world == 1 and not dry and not args.no_shard_proxy and B_total == TOTAL_CHAINS and not args.weak:
+        lm.set_job_items(B_total)
+        full_ms = 1e3 * elapsed / K
+        proxy = {"full_batch_ms_per_step": full_ms, "shards": {}}
+        for n_gpu in (2, 4, 8):
+            c = B_total // n_gpu
+            pj = Job(lm, 0, c)
+            keep = pj.run(2)
+            torch.cuda.synchronize(dev)
+            kp = max(3, min(K, 10))
+            t0 = time.perf_counter()
+            keep = pj.run(kp)
+            torch.cuda.synchronize(dev)
+            ms = 1e3 * (time.perf_counter() - t0) / kp
+            proxy["shards"][str(n_gpu)] = {"chains_per_gpu": c, "token_rows": c * T, "steps": kp, "ms_per_step": ms,
+                                           "efficiency_vs_linear": full_ms / n_gpu / ms,
+                                           "predicted_whole_node_positions_per_s": B_total * P / (ms * 1e-3)}
+        proxy["note"] = ("single-GPU proxy for the strong-scaling curve (no 8-GPU node on this pool): ms/step of a 1/N shard of the "
+                         "256-chain job with the job's kernel choices; predicted whole-node rate = 256 x P / that time; "
+                         "tools/shard_regime.py --engine is the stand-alone form")
+        out["shard_proxy"] = proxy
 
     # ---- N = 1 extras: strict-mode leg, config 1 on the GPU, CPU baseline ------------------------------------------------
     lm_strict = None
@@ -641,6 +778,27 @@ def main():
         out["msa"] = {"config4": {k_: c4[k_] for k_ in keep4}, "config5": {k_: c5[k_] for k_ in keep5},
                       "config5_one_template_per_call": {k_: c5_1[k_] for k_ in keep5},
                       "weights": "synthetic ESM-MSA-1b (12 layers, d=768), same scale as above"}
+        if not args.no_strict:
+            # north_star's 1e-3 for the ESM-MSA-1b configurations too: the strict engine's throughput on configs 4 and 5 (one
+            # step / one template), with its max |logit error| against the fp32 oracle measured on one config-4 alignment of the
+            # same weights (the bf16 engine's beside it); config 5's 128 x 513 shape against the oracle: tests/test_gpu_config5_oracle.py
+            mws, mls, _ = bench_msa.build("fp32", str(dev), realistic=True)
+            _lib.check(L_.pg_engine_set_stream(mls.handle, ctypes.c_void_p(stream.cuda_stream)))
+            chk4 = bench_msa.logit_check({"bf16": mlm, "fp32": mls}) if not args.no_cpu_baseline else {}
+            s4 = bench_msa.run_config4(mws, mls, mcfg, steps=1, warmup=1, precision="fp32", dev=dev)
+            s5 = bench_msa.run_config5(mws, mls, mcfg, templates=1, precision="fp32", dev=dev, max_batch=1)
+            e32, e16 = chk4.get("fp32_max_abs_logit_err"), chk4.get("bf16_max_abs_logit_err")
+
+            def at_tol(v, ms_key, ms):
+                return {"value": v, "unit": "sampled positions/s", ms_key: ms, "mode": "PG_PREC_FP32 (strict)", "tolerance": 1e-3,
+                        "max_abs_logit_err": e32, "meets_tolerance": (bool(e32 < 1e-3) if e32 is not None else None),
+                        "headline_mode_max_abs_logit_err": e16,
+                        "headline_mode_meets_tolerance": (bool(e16 < 1e-3) if e16 is not None else None)}
+            out["msa"]["config4"]["value_at_tolerance"] = at_tol(s4["value"], "ms_per_step", s4["ms_per_step"])
+            out["msa"]["config5"]["value_at_tolerance"] = at_tol(s5["value"], "ms_per_template_forward", s5["ms_per_template_forward"])
+            out["msa"]["config5"]["value_at_tolerance"]["templates_per_call"] = 1
+            out["msa"]["logit_check"] = chk4
+            del mls, mws
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -37,11 +37,21 @@ def msa_flops_per_forward(cfg, B, R, C):
     return n_tok * (nl * (2.0 * (8 * d * d + 2 * d * f) + 4.0 * C * d + 4.0 * R * d))
 
 
+_SD_CACHE = {}
+
+
+def state_dict(realistic=True):
+    """The seeded synthetic ESM-MSA-1b weights every leg of this file runs with (one copy per process)."""
+    if realistic not in _SD_CACHE:
+        kw = dict(std=0.025, embed_std=0.3, ln_jitter=0.1) if realistic else {}
+        _SD_CACHE[realistic] = weights.synthetic_state_dict(dict(weights.MSA1B_CONFIG), seed=0, **kw)
+    return _SD_CACHE[realistic]
+
+
 def build(precision="bf16", device="cuda:0", realistic=True):
     """(wrapper, engine, cfg): ESM-MSA-1b with seeded synthetic weights (realistic = logit std ~ 10, as the parity tests use)."""
     cfg = dict(weights.MSA1B_CONFIG)
-    kw = dict(std=0.025, embed_std=0.3, ln_jitter=0.1) if realistic else {}
-    sd = weights.synthetic_state_dict(cfg, seed=0, **kw)
+    sd = state_dict(realistic)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         wrapper = models.ESM_MSA1(state_dict=sd, config=cfg, precision=precision)
@@ -148,6 +158,29 @@ def run_config5(wrapper, lm, cfg, templates=4, precision="bf16", dev=None, max_b
                                    % (templates, R, L, steps, passes, burn_in, min(max_batch, templates))},
             "model_tflops": fl / el / 1e12, "frac_of_bf16_mfma_peak": tf / MFMA_BF16_PEAK_TFLOPS,
             "time_split_ms_per_forward": split}
+
+
+def logit_check(engines, R=32, L=256, P=25, realistic=True):
+    """max |logit error| of each engine in `engines` ({mode name: NativeMaskedLM}) against the numpy fp32 oracle
+    (oracle/msa_forward.py -- the checker, never the product) on ONE config-4 alignment (depth 32 x 257 columns, P = 25 <mask> per
+    row) of THIS file's weights, at the masked rows: the figure north_star's 1e-3 tolerance is held against.  ~10-20 s of host time."""
+    from oracle.msa_forward import MsaConfig, msa_forward
+    sd = state_dict(realistic)
+    rng = np.random.default_rng(77)
+    tok = random_msa_tokens(rng, list(range(4, 24)) + [30], 1, R, L).astype(np.int64)
+    for r in range(R):
+        tok[0, r, rng.choice(np.arange(1, L + 1), P, replace=False)] = 32
+    t0 = time.perf_counter()
+    want = msa_forward(sd, MsaConfig(), tok)
+    out = {"alignment": "1 x %d x %d (config 4's MSA shape), %d <mask> per row" % (R, L + 1, P), "rows_checked": int((tok == 32).sum()),
+           "logit_std": float(want.std()), "checker": "oracle/msa_forward.py (numpy fp32)", "oracle_seconds": time.perf_counter() - t0}
+    m = tok == 32
+    for name, lm in engines.items():
+        got = lm.forward_logits(tok.astype(np.int32))
+        err = np.abs(got[m] - want[m])
+        out[name + "_max_abs_logit_err"] = float(err.max())
+        out[name + "_mean_abs_logit_err"] = float(err.mean())
+    return out
 
 
 def main():

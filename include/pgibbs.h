@@ -258,6 +258,17 @@ int pg_comm_rank(const pg_comm*);
 int pg_comm_world(const pg_comm*);
 int pg_gather_tokens(pg_comm*, void* hip_stream, const int32_t* d_local, int64_t rows, int width, const int64_t* counts,
                      int32_t* d_out);
+/* Rehearsal of pg_gather_tokens without GPUs (tests only): the SAME bookkeeping -- which form, block size, scratch layout, per-rank
+ * pack offsets -- on HOST buffers, with the all-gather injected by the caller: allgather(ctx, send, recv, n) must fill recv with
+ * the `world` ranks' n int32 values in rank order and return 0.  One call per simulated rank (e.g. one thread each); world sizes
+ * 2 ... 8 with ragged and empty shards run in the CPU suite this way (tests/test_gather_rehearsal.py).  pg_dbg_gather_plan reports
+ * the plan itself: out7 = {equal form?, nothing to move?, rows of a padded block, bytes per row, bytes per block, scratch bytes,
+ * bytes of the gathered output}, out_off_bytes[world] = byte offset of every rank's rows in the output (may be NULL). */
+typedef int (*pg_allgather_fn)(void* ctx, const void* send, void* recv, size_t n_int32);
+int pg_dbg_gather_tokens_host(int rank, int world, const int32_t* local, int64_t rows, int width, const int64_t* counts,
+                              int force_padded, pg_allgather_fn allgather, void* ctx, int32_t* out);
+int pg_dbg_gather_plan(int rank, int world, int64_t rows, int width, const int64_t* counts, int force_padded, int64_t* out7,
+                       int64_t* out_off_bytes);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * HIP-event timing of kernel classes on the engine's stream (bench.py's roofline figure).

@@ -102,6 +102,8 @@ SIGNATURES = [
     ("pg_comm_rank", c_int, [c_void_p]),
     ("pg_comm_world", c_int, [c_void_p]),
     ("pg_gather_tokens", c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(c_int64), c_void_p]),
+    ("pg_dbg_gather_tokens_host", c_int, [c_int, c_int, c_void_p, c_int64, c_int, POINTER(c_int64), c_int, c_void_p, c_void_p, c_void_p]),
+    ("pg_dbg_gather_plan", c_int, [c_int, c_int, c_int64, c_int, POINTER(c_int64), c_int, POINTER(c_int64), POINTER(c_int64)]),
     ("pg_prof_enable", c_int, [c_void_p, c_int]),
     ("pg_prof_reset", c_int, [c_void_p]),
     ("pg_prof_get", c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64)]),
