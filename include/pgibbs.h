@@ -174,7 +174,9 @@ int pg_esm_gibbs_run(pg_engine*, int32_t* tokens_inout, int B, int T, const int3
  * enqueueing on the engine's stream; every buffer (incl. d_target_idx) must stay valid until pg_engine_synchronize.  Single short
  * chains (<= 32 token rows) may run on a persistent launch whose device-wide barriers can time out when the GPU is shared; such
  * calls are logged with a snapshot of their token rows, and the next pg_esm_gibbs_run_device / pg_engine_synchronize that sees
- * the timeout restores the rows and runs the logged calls again on the per-layer launches (same results, one warning). */
+ * the timeout restores the rows and runs the logged calls again on the per-layer launches (same results, one warning).
+ * Consequence for the caller: between two synchronisations nothing but pg_*_device calls of this engine may write a token buffer
+ * that was handed to such a call -- the replay restores the snapshot taken at the first logged call and re-runs only those. */
 int pg_esm_gibbs_run_device(pg_engine*, int32_t* d_tokens_inout, int B, int T, const int32_t* d_target_idx,
                             int n_iters, int P, const pg_sample_params* params, float* d_sampled_logits,
                             int32_t* d_sampled_tokens);
@@ -276,6 +278,10 @@ int pg_dbg_gather_plan(int rank, int world, int64_t rows, int width, const int64
 int pg_prof_enable(pg_engine*, int on);
 int pg_prof_reset(pg_engine*);
 int pg_prof_get(pg_engine*, const char* kernel_class, double* total_ms, int64_t* launches);
+/* the kernels the GEMM dispatch picked for the profiled launches of a class ("gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2",
+ * "gemm_other", "head"): distinct labels such as "pp192 220t" (220 tiles of 192 x 256) or "tile64 400t x4k" (64 x 64 tiles,
+ * 4 K-splits), separated by " | ", into buf. */
+int pg_prof_get_kernels(pg_engine*, const char* kernel_class, char* buf, int buf_bytes);
 
 /* ---- kernel-level debug entry points (parity tests call individual kernels through these) --- */
 /* out[M][N] = x[M][K] @ w[N][K]^T + bias (fp32 host buffers; computed in `precision`); epi: 0 none, 1 gelu,

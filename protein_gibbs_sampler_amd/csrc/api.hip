@@ -182,16 +182,21 @@ int pg_esm_gibbs_run_device(pg_engine* h, int32_t* d_tokens_inout, int B, int T,
   if (rc) return rc;
   Engine& e = h->e;
   DeviceGuard g(e.device);
-  if (B > 0 && n_iters > 0 && T >= 1 && e.chain_may_run(B, T)) {
-    if (*e.chain_err) {                   // an earlier asynchronous call has reported a timeout: repair before building on its tokens
-      PG_HIP(hipStreamSynchronize(e.stream));
-      rc = e.chain_check();
-      if (rc && !e.chain_replay_ok) return rc;
-      e.chain_retry = false;
-    }
-    if (e.chain_may_run(B, T) && (rc = e.chain_log_call(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens)))
-      return rc;
+  // An earlier asynchronous call has reported a barrier timeout of the persistent trunk: repair (restore the logged token rows,
+  // run the logged calls again on the per-layer launches) BEFORE this call is queued on top of those tokens -- whatever this
+  // call's own shape is (round 6, ADVICE r05: a following call with B*T > 32 on the same tokens used to be enqueued on the
+  // corrupted rows, and the later replay then re-ran only the logged calls).  Contract (pgibbs.h): between synchronisations no work
+  // other than pg_*_device calls of this engine may touch a token buffer that such a call has been given -- the replay restores
+  // the snapshot taken at the first logged call.
+  if (!e.chain_log.empty() && e.chain_err && *e.chain_err) {
+    PG_HIP(hipStreamSynchronize(e.stream));
+    rc = e.chain_check();
+    if (rc && !e.chain_replay_ok) return rc;
+    e.chain_retry = false;
   }
+  if (B > 0 && n_iters > 0 && T >= 1 && e.chain_may_run(B, T) &&
+      (rc = e.chain_log_call(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens)))
+    return rc;
   return e.esm_gibbs_device(d_tokens_inout, B, T, d_target_idx, n_iters, P, params, d_sampled_logits, d_sampled_tokens);
 }
 
@@ -492,6 +497,22 @@ int pg_prof_get(pg_engine* h, const char* kernel_class, double* total_ms, int64_
     }
   *total_ms = ms;
   *launches = n;
+  return PG_OK;
+}
+
+int pg_prof_get_kernels(pg_engine* h, const char* kernel_class, char* buf, int buf_bytes) {
+  if (!h || !kernel_class || !buf || buf_bytes < 2) return fail(PG_ERR_INVALID, "pg_prof_get_kernels: null argument");
+  static const char* names[PC_COUNT] = {"gemm_other", "attention", "layernorm", "embed", "head", "sample", "gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2"};
+  int cls = -1;
+  for (int i = 0; i < PC_COUNT; ++i)
+    if (!strcmp(names[i], kernel_class)) cls = i;
+  if (cls < 0) return fail(PG_ERR_INVALID, std::string("unknown kernel class ") + kernel_class);
+  std::vector<std::string> seen;
+  for (auto& r : h->e.prof.recs)
+    if (r.cls == cls && !r.kernels.empty() && std::find(seen.begin(), seen.end(), r.kernels) == seen.end()) seen.push_back(r.kernels);
+  std::string out;
+  for (auto& k : seen) out += (out.empty() ? "" : " | ") + k;
+  snprintf(buf, (size_t)buf_bytes, "%s", out.c_str());
   return PG_OK;
 }
 

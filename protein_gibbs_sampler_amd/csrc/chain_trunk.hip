@@ -665,6 +665,7 @@ int launch_chain_trunk(hipStream_t s, const PgChainTrunkArgs& a, int M, int d_mo
   if (n_cu < 1) return kChainTrunkUnfit;
   const int G = g_env > 0 && g_env <= n_cu ? g_env : n_cu;
   dim3 grid(G), block(512);
+  note_kernel("chain_trunk (all layers, persistent)", G);
 #define PG_CT(MTV, NK) hipLaunchKernelGGL((chain_trunk_kernel<MTV, NK>), grid, block, 0, s, a)
 #define PG_CT_NK(MTV)                          \
   switch (d_model / 256) {                     \

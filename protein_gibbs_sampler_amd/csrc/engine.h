@@ -18,7 +18,7 @@ struct DevBuf {
 };
 
 struct Prof {
-  struct Rec { int cls; hipEvent_t a, b; };
+  struct Rec { int cls; hipEvent_t a, b; std::string kernels; };   // kernels: what the GEMM dispatch noted (pg::note_kernel)
   bool on = false;
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
@@ -106,6 +106,7 @@ struct Engine {
   DevBuf chain_snap;
   static constexpr size_t kChainSnapBytes = 128, kChainLogMax = 64;
   bool chain_may_run(int B, int T) const;                    // would a forward of this shape take the persistent launch?
+  int64_t batch_rows_for(int B, int T) const { return job_batch(B) * T; }
   int chain_log_call(int32_t* d_tok, int B, int T, const int32_t* d_idx, int n_iters, int P, const pg_sample_params* sp, float* lg,
                      int32_t* st);
   // host-pinned word the draw / log-probability kernels set when a logit row is not finite (an fp16 operand that overflowed

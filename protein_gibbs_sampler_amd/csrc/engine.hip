@@ -28,6 +28,17 @@ int fail(int code, const std::string& msg) {
 }
 const char* last_error_cstr() { return g_last_error.c_str(); }
 
+static thread_local std::string g_noted;
+void note_kernel(const char* label, long tiles, int splits) {
+  if (g_noted.size() > 512) return;
+  if (!g_noted.empty()) g_noted += " + ";
+  g_noted += label;
+  if (tiles >= 0) g_noted += " " + std::to_string(tiles) + "t";
+  if (splits > 1) g_noted += " x" + std::to_string(splits) + "k";
+}
+const std::string& noted_kernels() { return g_noted; }
+void clear_noted_kernels() { g_noted.clear(); }
+
 // ------------------------------------------------------------------------------------------------
 // bumped whenever any workspace buffer is (re)allocated: a captured graph holds raw pointers and must be re-captured
 static uint64_t g_alloc_epoch = 0;
@@ -74,10 +85,11 @@ void Prof::destroy() {
 template <typename F> int Engine::timed(int cls, F&& f) {
   if (!prof.on) return f();
   hipEvent_t a = prof.get(), b = prof.get();
+  clear_noted_kernels();
   PG_HIP(hipEventRecord(a, stream));
   int rc = f();
   PG_HIP(hipEventRecord(b, stream));
-  prof.recs.push_back({cls, a, b});
+  prof.recs.push_back({cls, a, b, noted_kernels()});
   return rc;
 }
 
@@ -304,8 +316,16 @@ int Engine::range_check() {
                                 : "non-finite logits (NaN / inf in the weights or an overflow in the forward); the results of this call are invalid");
 }
 
+// esm_trunk's own predicate for the persistent launch (a call that would not take it is not worth a snapshot, a log entry and a
+// forced synchronisation every kChainLogMax calls): no <pad> batch, the rows fit one or two 16-row MFMA tiles, and the
+// LayerNorm-folding weight-streaming GEMMs accept the shape
 bool Engine::chain_may_run(int B, int T) const {
-  return chain_layers && chain_err && !chain_disabled && T >= 1 && T <= 32 && (int64_t)B * T <= 32;
+  if (!(chain_layers && chain_err && !chain_disabled && !esm_pad_in_batch && T >= 1 && T <= 32 && (int64_t)B * T <= 32)) return false;
+  const int64_t M = (int64_t)B * T;
+  const int Mi = round_up((int)M, 16);
+  const int d = cfg.d_model, f = cfg.d_ffn;
+  if (batch_rows_for(B, T) > 2048 && Mi < 64) return false;                  // a tiny shard of a big job runs 64-row tiles (sel_gemm_rows)
+  return gemm_ln_skinny_ok(Mi, 3 * d, d) && gemm_ln_skinny_ok(Mi, f, d) && OPS(chain_trunk_ok, Mi, d, f, cfg.n_heads);
 }
 
 int Engine::chain_log_call(int32_t* d_tok, int B, int T, const int32_t* d_idx_, int n_iters, int P, const pg_sample_params* sp,
@@ -332,6 +352,10 @@ int Engine::chain_check() {
   chain_replay_ok = false;
   if (!chain_err || !*chain_err) { chain_log.clear(); return PG_OK; }
   *chain_err = 0;
+  // the timed-out launch may have left garbage activations behind, and the draw / log-probability kernels that ran on them may
+  // have raised the non-finite flag: that verdict belongs to the abandoned launch, not to the replay (or the caller's retry) that
+  // follows -- they raise it again if the logits really are non-finite
+  if (range_err) *range_err = 0;
   if (chain_sync.p) (void)hipMemsetAsync(chain_sync.p, 0, chain_sync.bytes, stream);
   if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; graph_key.clear(); }   // it holds the persistent launch
   if (!chain_disabled)

@@ -632,6 +632,10 @@ static int launch_pp(hipStream_t s, const bf16_t* X, const bf16_t* W, const floa
                         ? round_sync_words() : nullptr;
   const int n_tail = (tail_last || rsync) ? -n_tail_abs : n_tail_abs;
   dim3 grid(n_tiles + n_tail_abs), block(512);
+  if (!abl) {
+    note_kernel(tile_rows == 192 ? "pp192x256" : "pp256x256", n_tiles);
+    if (n_tail_abs) note_kernel("tail64", n_tail_abs);
+  }
 #define PG_PP_ARGS X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0, rsync
   if (abl) {   // ablations: EPI_BF16 only
     if (abl == 1) hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI_BF16, 1>), grid, block, 0, s, PG_PP_ARGS);
@@ -990,6 +994,7 @@ int launch_gemm_ln_skinny(hipStream_t s, const float* X, int ldx, const float* g
   const int nb = nb_env ? nb_env : ((N / 16 > n_cu && N % 32 == 0) ? 2 : 1);
   if (nb == 2 && N % 32) return fail(1, "gemm_ln_skinny: N must be a multiple of 32 for two feature blocks per workgroup");
   dim3 grid(N / (16 * nb)), block(512);
+  note_kernel("ln+skinny8w", N / (16 * nb));
 #define PG_LNS(MTV, E, NK)                                                                                                       \
   do {                                                                                                                           \
     if (nb == 2) hipLaunchKernelGGL((gemm_ln_skinny_kernel<MTV, E, NK, 2>), grid, block, 0, s, X, ldx, gamma, beta, eps, W, bias, out, K, ldw, ldo); \
@@ -1021,6 +1026,7 @@ static int launch_skinny_mt(hipStream_t s, const bf16_t* X, const bf16_t* W, con
   // 32-wide k-steps and the m-tile count keeps the register footprint small
   const bool w8 = (K % 256 == 0) && MT <= 4;
   dim3 grid(N / 16, splits), block(w8 ? 512 : 256);
+  note_kernel(w8 ? "skinny8w" : "skinny4w", N / 16, splits);
 #define PG_GEMM_CASE(E)                                                                                              \
   case E:                                                                                                            \
     if (w8) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<MT, E, 8>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, split_stride); \
@@ -1046,6 +1052,7 @@ static int launch_cfg(hipStream_t s, const bf16_t* X, const bf16_t* W, const flo
                       int K, int ldx, int ldw, int ldo, int epi, int splits = 1, long split_stride = 0) {
   const int tiles_m = M / BM, tiles_n = N / BN, n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles, splits), block((BM / WM) * (BN / WN) * 64);
+  note_kernel(BM == 64 ? "tile64x64" : (BM == 128 ? "tile128x128" : "tile256x256-lockstep"), n_tiles, splits);
 #define PG_GEMM_CASE(E)                                                                                              \
   case E:                                                                                                            \
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, E>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, \

@@ -340,6 +340,8 @@ int launch_gemm_w16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float
   static const int gm_env = [] { const char* e = getenv("PGIBBS_GEMM_GM"); return e ? atoi(e) : 0; }();
   const int gm = gm_env ? gm_env : (K >= 4096 ? 2 : 4);
   dim3 grid(n_tiles + n_tail_abs), block(1024);
+  note_kernel("w16-256x256", n_tiles);
+  if (n_tail_abs) note_kernel("tail64", n_tail_abs);
 #define PG_W16_CASE(E)                                                                                                     \
   case E:                                                                                                                  \
     if (gm == 2) hipLaunchKernelGGL((gemm_bf16_w16_kernel<E, 2, 0>), grid, block, 0, s, X, W, bias, out, K, ldx, ldw, ldo, tiles_n, n_tiles, n_tail, tail_m0); \

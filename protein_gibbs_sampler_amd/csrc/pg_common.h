@@ -10,6 +10,12 @@ namespace pg {
 // ---- errors ---------------------------------------------------------------------------------
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+// Which kernel did the dispatch pick?  Every GEMM launcher notes a short label ("pp256 165t", "tile64 x4 splits" ...) right before
+// its launch; Engine::timed() attaches the labels noted inside a timed call to that call's record (pg_prof_get_kernels: the
+// "kernel chosen per GEMM" column of tools/batch_sweep.py).  Thread-local, a few bytes per launch, no effect on the launch.
+void note_kernel(const char* label, long tiles = -1, int splits = 0);
+const std::string& noted_kernels();
+void clear_noted_kernels();
 
 #define PG_HIP(expr)                                                                                  \
   do {                                                                                                \

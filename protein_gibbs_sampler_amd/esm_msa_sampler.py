@@ -240,7 +240,7 @@ class ESM_MSA_sampler():
                     finally:
                         self.model.model.set_job_items(0)
                 tok = sharding.run_sharded(ctx, np.ascontiguousarray(batch.numpy(), dtype=np.int32), table,
-                                           generation_round * batch_size * num_sequences, num_sequences, run_block, self.device)
+                                           generation_round * batch_size * num_sequences, num_sequences, run_block, self.device, guard=self.model.model)
                 batch = torch.from_numpy(tok.astype(np.int64))
             elif native:
                 tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)

@@ -211,7 +211,7 @@ class ESM_sampler():
                     finally:
                         self.model.model.set_job_items(0)
                 tok = sharding.run_sharded(ctx, np.ascontiguousarray(batch.numpy(), dtype=np.int32), table,
-                                           batch_n * batch_size, 1, run_block, self.device)
+                                           batch_n * batch_size, 1, run_block, self.device, guard=self.model.model)
                 batch = torch.from_numpy(tok.astype(np.int64))
             elif native:
                 tok = np.ascontiguousarray(batch.numpy(), dtype=np.int32)

@@ -72,16 +72,31 @@ def sync_host_rng(ctx):
     random.setstate(broadcast_object(ctx, random.getstate()))
 
 
-def run_sharded(ctx, tokens, table, row_id_base, rows_per_item, run_fn, device=None):
+def run_sharded(ctx, tokens, table, row_id_base, rows_per_item, run_fn, device=None, guard=None):
     """One batch over the ranks: item block [lo, hi) of `tokens` [B, ...] and `table` [iters, B, ...] goes through
     run_fn(local_tokens, local_table, local_row_id_base) (in place), then ONE all-gather rebuilds the whole token buffer
-    on every rank.  rows_per_item = Philox row ids consumed per item (1 per chain, R per MSA)."""
+    on every rank.  rows_per_item = Philox row ids consumed per item (1 per chain, R per MSA).
+    guard: the NativeMaskedLM behind run_fn.  With precision="auto" on fp16 operands a block whose logits leave the fp16 range is
+    run again in bf16 (engine.py); the single-GPU call would then have run the WHOLE batch in bf16, so the ranks agree first (one
+    all-gather of a flag) and, if any block overflowed, every other rank repeats its block in bf16 too -- the gathered result
+    stays bit-identical with the single-GPU run."""
     import torch
     B = tokens.shape[0]
     lo, hi = shard_range(B, ctx.world, ctx.rank)
     local = np.ascontiguousarray(tokens[lo:hi])
+    agree = guard is not None and bool(getattr(guard, "auto_fp16", False))
+    if agree:
+        guard.take_fell_back()
     if hi > lo:
         run_fn(local, np.ascontiguousarray(table[:, lo:hi]), row_id_base + lo * rows_per_item)
+    if agree:
+        mine = guard.take_fell_back()
+        flags = [None] * ctx.world
+        ctx.dist.all_gather_object(flags, bool(mine))
+        if any(flags) and not mine and hi > lo:
+            local = np.ascontiguousarray(tokens[lo:hi])
+            with guard.forced_bf16():
+                run_fn(local, np.ascontiguousarray(table[:, lo:hi]), row_id_base + lo * rows_per_item)
     counts = [shard_range(B, ctx.world, r)[1] - shard_range(B, ctx.world, r)[0] for r in range(ctx.world)]
     t = torch.from_numpy(local)
     on_gpu = ctx.dist.get_backend() != "gloo"

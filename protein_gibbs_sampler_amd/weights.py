@@ -203,20 +203,25 @@ _ARCH_NAME = {_lib.PG_ARCH_ESM1B: "ESM-1b", _lib.PG_ARCH_ESM1: "ESM-1", _lib.PG_
 
 
 def checkpoint_args(blob):
-    """The hyper-parameters a fair-esm v1 checkpoint carries ({"args": Namespace | dict}) with the `encoder_` / `decoder_` prefixes
-    dropped, as fair-esm's loader drops them before it builds the module (its lambda `pra`, esm/pretrained.py [recalled]):
-    `encoder_embed_dim` -> `embed_dim`, `decoder_layers` -> `layers`, ...  {} when the file has none."""
+    """The hyper-parameters a fair-esm v1 checkpoint carries ({"args": Namespace | dict}) with ONE prefix dropped per
+    architecture, as fair-esm's loader drops it before it builds the module (its lambda `pra`, esm/pretrained.py [recalled]):
+    `encoder_` for roberta_large and msa_transformer, `decoder_` for protein_bert_base -- `encoder_embed_dim` -> `embed_dim`,
+    `decoder_layers` -> `layers`, ...  Keys with the other prefix stay as they are (they are leftovers of the training namespace
+    that fair-esm never reads), so a collision such as `encoder_embed_dim` vs `decoder_embed_dim` cannot be resolved by dict
+    order.  {} when the file has none."""
     a = blob.get("args") if isinstance(blob, dict) else None
     if a is None:
         return {}
     raw = dict(a) if isinstance(a, dict) else dict(vars(a))
+    pre = "decoder_" if raw.get("arch") == "protein_bert_base" else "encoder_"
     out = {}
     for k, v in raw.items():
-        for pre in ("encoder_", "decoder_"):
-            if pre in k:
-                k = "".join(k.split(pre)[1:])
-                break
-        out[k] = v
+        if pre in k:
+            stripped = "".join(k.split(pre)[1:])
+            out[stripped] = v                      # the prefixed form wins over an unprefixed leftover of the same name
+    for k, v in raw.items():
+        if pre not in k:
+            out.setdefault(k, v)
     return out
 
 
@@ -225,8 +230,14 @@ def config_from_checkpoint(args, state_names, base_cfg, explicit=False):
     checkpoint's own hyper-parameters -- what `esm.pretrained.*` builds the module from in the reference
     (/root/reference/src/pgen/models.py:61-86) -- instead of a fixed dict per wrapper.  Read: arch, embed_dim, layers,
     attention_heads, ffn_embed_dim, max_positions, token_dropout, emb_layer_norm_before, final_bias, embed_positions_msa.
-    Anything the engine does not implement raises ValueError naming the flag; with explicit=True (the caller passed `config=`)
-    a disagreement between that config and the file raises too instead of silently picking one."""
+    What fair-esm HONOURS for that architecture and the engine does not implement raises ValueError naming the flag; flags fair-esm
+    itself never reads for the architecture (released `args` are the internal training namespace and may carry such leftovers:
+    `token_dropout` in an msa_transformer file -- MSATransformer has no token dropout --, `final_bias` outside ESM-1 --
+    RobertaLMHead always has a bias --, an `emb_layer_norm_before` value that the tensors contradict -- fair-esm decides it from the
+    tensors) are ignored with a warning, as the loader the reference relies on would load the file.  With
+    explicit=True (the caller passed `config=`) a disagreement between that config and the file raises instead of silently
+    picking one.  NOT validated against the args of the real released .pt files (none are available offline)."""
+    import warnings
     cfg = dict(base_cfg)
     arch = args.get("arch")
     if arch is not None:
@@ -254,17 +265,28 @@ def config_from_checkpoint(args, state_names, base_cfg, explicit=False):
     has_ln_before = any(n.startswith("emb_layer_norm_before") for n in state_names)
     if cfg["arch"] in (_lib.PG_ARCH_ESM1B, _lib.PG_ARCH_MSA1B):
         # fair-esm decides this flag from the tensors (`has_emb_layer_norm_before`), not from args
-        if args.get("emb_layer_norm_before") is False or not has_ln_before:
+        if not has_ln_before:
             raise ValueError("checkpoint was trained without emb_layer_norm_before: the %s engine always applies it (every released "
                              "ESM-1b / ESM-1v / ESM-MSA-1b checkpoint has it)" % _ARCH_NAME[cfg["arch"]])
+        if args.get("emb_layer_norm_before") is False:
+            warnings.warn("checkpoint args say emb_layer_norm_before=False but the file holds emb_layer_norm_before.*: going by the "
+                          "tensors, as fair-esm does")
         if args.get("final_bias") is False:
-            raise ValueError("final_bias=False: the engine's LM head adds lm_head.bias")
-    elif has_ln_before or args.get("emb_layer_norm_before"):
-        raise ValueError("ESM-1 checkpoint with emb_layer_norm_before: the ESM-1 engine has no embedding LayerNorms")
+            warnings.warn("final_bias=False in a %s checkpoint is ignored: only ESM-1's embed_out reads it, RobertaLMHead always has "
+                          "a bias" % _ARCH_NAME[cfg["arch"]])
+    elif has_ln_before:
+        raise ValueError("ESM-1 checkpoint with emb_layer_norm_before tensors: the ESM-1 engine has no embedding LayerNorms")
+    elif args.get("emb_layer_norm_before"):
+        warnings.warn("checkpoint args say emb_layer_norm_before=True but the file holds no such tensors: going by the tensors, as "
+                      "fair-esm does")
     if cfg["arch"] == _lib.PG_ARCH_MSA1B and args.get("embed_positions_msa") is False:
         raise ValueError("embed_positions_msa=False: the MSA engine adds msa_position_embedding (esm_msa1b_t12_100M_UR50S has it)")
-    if cfg["arch"] != _lib.PG_ARCH_ESM1B and args.get("token_dropout"):
-        raise ValueError("token_dropout=True in a %s checkpoint: only the ESM-1b architecture implements it" % _ARCH_NAME[cfg["arch"]])
+    if args.get("token_dropout"):
+        if cfg["arch"] == _lib.PG_ARCH_ESM1:
+            raise ValueError("token_dropout=True in an ESM-1 checkpoint: fair-esm's ProteinBertModel would apply it, the ESM-1 engine "
+                             "does not implement it (none of esm1_t6 / t12 / t34 sets it)")
+        if cfg["arch"] == _lib.PG_ARCH_MSA1B:
+            warnings.warn("token_dropout=True in an msa_transformer checkpoint is ignored: fair-esm's MSATransformer never reads it")
     n_layers_seen = 1 + max([int(m.group(1)) for m in (re.match(r"layers\.(\d+)\.", n) for n in state_names) if m] or [-1])
     if n_layers_seen and n_layers_seen != cfg["n_layers"]:
         if "n_layers" in take or explicit:

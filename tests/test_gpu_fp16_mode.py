@@ -213,8 +213,9 @@ def test_auto_precision_probe_moves_an_overflowing_checkpoint_to_bf16():
 
 def test_auto_precision_falls_back_inside_a_call_and_restores_the_tokens(monkeypatch):
     """Without the probe (PGIBBS_F16_PROBE=0: stands for an overflow only some later input triggers) the Gibbs call itself reports
-    PG_ERR_RANGE before it writes the caller's tokens; the wrapper rebuilds the engine in bf16, restores the tokens and runs the
-    call again: same tokens and emitted logits as a bf16 engine, one warning."""
+    PG_ERR_RANGE before it writes the caller's tokens; the wrapper restores the tokens and runs THAT CALL again on the bf16 engine
+    of the same weights: same tokens and emitted logits as a bf16 engine, one warning.  Round 6: the object's mode
+    does not change -- later calls are again tried in fp16 (and, here, fall back again, silently)."""
     monkeypatch.setenv("PGIBBS_F16_PROBE", "0")
     cfg, sd, tok = _auto_setup(scale_fc1=1e5)
     table = np.stack([np.stack([np.random.default_rng(9 + i).choice(np.arange(1, 41), 4, replace=False) for _ in range(3)]) for i in range(2)]).astype(np.int32)
@@ -224,16 +225,138 @@ def test_auto_precision_falls_back_inside_a_call_and_restores_the_tokens(monkeyp
         lm = models.ESM1b(state_dict=sd, config=cfg).model.to("cuda:0")          # no probe, no warning yet
     assert lm.precision_name == "fp16"
     t_auto = tok.copy()
-    with pytest.warns(UserWarning, match="rebuilding it with bf16") as rec:
+    with pytest.warns(UserWarning, match="run again with bf16 operands") as rec:
         lg_auto, _ = lm.gibbs_run(t_auto, table, params, want_logits=True)
-    assert len(rec) == 1 and lm.precision_name == "bf16"
+    assert len(rec) == 1 and lm.precision_name == "fp16" and lm.fallbacks == 1 and lm.take_fell_back()
     ref = models.ESM1b(state_dict=sd, config=cfg, precision="bf16").model.to("cuda:0")
     t_ref = tok.copy()
     lg_ref, _ = ref.gibbs_run(t_ref, table, params, want_logits=True)
     assert np.array_equal(t_auto, t_ref) and np.array_equal(lg_auto.view(np.uint32), lg_ref.view(np.uint32))
     with warnings.catch_warnings():
-        warnings.simplefilter("error")                                           # stays on bf16: no second warning
-        lm.forward_logits(tok)
+        warnings.simplefilter("error")                                           # announced once
+        got = lm.forward_logits(tok)
+    assert lm.fallbacks == 2 and np.array_equal(got.view(np.uint32), ref.forward_logits(tok).view(np.uint32))
+
+
+def _msa_auto_setup():
+    from oracle.msa_forward import MsaConfig, synthetic_msa_weights
+    ck = dict(d_model=128, n_layers=2, n_heads=2, d_ffn=256, max_pos=640, max_rows=16)
+    sd = synthetic_msa_weights(MsaConfig(**ck), seed=4, std=0.08, embed_std=0.5, ln_jitter=0.1)
+    cfg = weights.make_config(weights.MSA1B_CONFIG, d_model=128, n_layers=2, d_ffn=256, max_positions=640, max_msa_rows=16)
+    rng = np.random.default_rng(8)
+
+    def msa(R, C):
+        t = rng.integers(4, 24, (1, R, C))
+        t[rng.random((1, R, C)) < 0.1] = 30
+        t[..., 0] = 0
+        return t.astype(np.int32)
+    return cfg, sd, msa
+
+
+def test_auto_precision_routes_by_the_calls_own_shape_not_by_call_order():
+    """an alignment wider than 576 columns used to flip the whole object to bf16, so every LATER narrow
+    alignment was sampled in bf16 too -- results depended on call order (and, sharded, on the rank).  Now the wide call alone goes
+    to the bf16 engine: wide == a bf16 engine's result, narrow == a fresh fp16 engine's result, in either order, no warning."""
+    cfg, sd, msa = _msa_auto_setup()
+    wide, narrow, padded = msa(3, 600), msa(3, 40), msa(3, 40)
+    padded[0, 2, 30:] = 1                                                      # <pad>: the other shape the fp16 kernels lack
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        a = models.ESM_MSA1(state_dict=sd, config=cfg).model.to("cuda:0")
+        b = models.ESM_MSA1(state_dict=sd, config=cfg).model.to("cuda:0")
+        w_a, p_a, n_a = a.forward_logits(wide), a.forward_logits(padded), a.forward_logits(narrow)       # wide first
+        n_b, w_b = b.forward_logits(narrow), b.forward_logits(wide)                                      # narrow first
+    assert a.precision_name == b.precision_name == "fp16" and a.fallbacks == b.fallbacks == 0
+    f16 = models.ESM_MSA1(state_dict=sd, config=cfg, precision="fp16").model.to("cuda:0")
+    bf = models.ESM_MSA1(state_dict=sd, config=cfg, precision="bf16").model.to("cuda:0")
+    for got in (n_a, n_b):
+        assert np.array_equal(got.view(np.uint32), f16.forward_logits(narrow).view(np.uint32))
+    for got in (w_a, w_b):
+        assert np.array_equal(got.view(np.uint32), bf.forward_logits(wide).view(np.uint32))
+    assert np.array_equal(p_a.view(np.uint32), bf.forward_logits(padded).view(np.uint32))
+
+
+def _auto_shard_worker(rank, world, port, q):
+    import os
+    import random
+    import torch
+    import torch.distributed as dist
+    from protein_gibbs_sampler_amd import esm_msa_sampler
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _auto_shard_job(True, 3 if rank == 0 else 77)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _auto_shard_job(shard, seed):
+    import random
+    import torch
+    from protein_gibbs_sampler_amd import esm_msa_sampler
+    cfg, sd, msa = _msa_auto_setup()
+    inv = "LAGVSERTIDPKQNFYMHWC"
+    def rows(t):
+        return ["".join("-" if v == 30 else inv[v - 4] for v in r[1:]) for r in t[0]]
+    jobs = [rows(msa(3, 600)), rows(msa(3, 40)), rows(msa(3, 40)), rows(msa(3, 40))]      # rank 0: wide + narrow, rank 1: two narrow
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s = esm_msa_sampler.ESM_MSA_sampler(models.ESM_MSA1(state_dict=sd, config=cfg), device="cuda:0")
+    s.shard_over_ranks = shard
+    random.seed(seed)
+    torch.manual_seed(seed)
+    out = s.generate_single_batch(jobs, steps=3, passes=2, burn_in=1, target_index=0, k=1, max_batch=2)
+    return out, s.model.model.precision_name
+
+
+def test_sharded_auto_precision_with_a_wide_and_narrow_mix_equals_the_single_gpu_run():
+    """The invariant sharding exists to keep, under precision="auto": rank 0 holds the wide alignment (bf16 engine) and a narrow
+    one, rank 1 two narrow ones (fp16); both ranks return the single-process result, string for string (two gloo ranks sharing
+    this GPU)."""
+    import socket
+    import torch.multiprocessing as mp
+    want, mode = _auto_shard_job(False, 3)
+    assert mode == "fp16"
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_auto_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        assert got[rank][0] == want and got[rank][1] == "fp16"
+
+
+def test_batched_generate_single_overflow_is_repeated_template_by_template(monkeypatch):
+    """A batched generate_single call that reports PG_ERR_RANGE is repeated one template at a time: since a template's result is
+    that of a call on it alone, the outcome does not depend on how templates were grouped (or sharded).  The overflow is injected
+    (PGIBBS_F16_PROBE=0 + fc1 weights that drive GELU(fc1) past 65504 make EVERY template overflow): results == a bf16 engine's."""
+    monkeypatch.setenv("PGIBBS_F16_PROBE", "0")
+    cfg, sd, msa = _msa_auto_setup()
+    sd = {k: v.copy() for k, v in sd.items()}
+    for k in sd:
+        if k.endswith("fc1.weight"):
+            sd[k] *= 1e5 / max(1e-9, float(np.abs(sd[k]).max())) * 0.6
+    toks = np.concatenate([msa(3, 40), msa(3, 40)]).astype(np.int32)
+    idx = np.tile(np.array([[3, 9, 17]], dtype=np.int32), (2, 2, 1))
+    params = [_lib.make_sample_params(True, 32, 1, 0, None, list(range(4, 24)) + [30], rng_seed=5 + b) for b in range(2)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        auto = models.ESM_MSA1(state_dict=sd, config=cfg).model.to("cuda:0")
+        bf = models.ESM_MSA1(state_dict=sd, config=cfg, precision="bf16").model.to("cuda:0")
+        t_a, t_b = toks.copy(), toks.copy()
+        lg_a, st_a = auto.gibbs_single_batch_run(t_a, 2, 0, idx, [1, 0], params, True, True)
+        lg_b, st_b = bf.gibbs_single_batch_run(t_b, 2, 0, idx, [1, 0], params, True, True)
+    assert auto.fallbacks >= 1 and auto.precision_name == "fp16"
+    assert np.array_equal(t_a, t_b) and np.array_equal(st_a, st_b) and np.array_equal(lg_a.view(np.uint32), lg_b.view(np.uint32))
 
 
 def test_explicit_fp16_reports_the_overflow_instead_of_sampling_from_nan():

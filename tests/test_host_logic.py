@@ -392,13 +392,10 @@ def test_checkpoint_hyper_parameters_come_from_the_file(tmp_path):
 
 
 @pytest.mark.parametrize("arch,base,args,msg", [
-    ("roberta_large", "ESM1B", dict(emb_layer_norm_before=False), "emb_layer_norm_before"),
-    ("roberta_large", "ESM1B", dict(final_bias=False), "final_bias"),
     ("roberta_large", "ESM1B", dict(encoder_attention_heads=4), "head dimension 64"),
     ("roberta_large", "ESM1B", dict(encoder_layers=5), "holds 2 layers"),
     ("msa_transformer", "MSA1B", dict(embed_positions_msa=False), "embed_positions_msa"),
-    ("msa_transformer", "MSA1B", dict(token_dropout=True), "token_dropout"),
-    ("protein_bert_base", "ESM1_T6", dict(emb_layer_norm_before=True), "embedding LayerNorms"),
+    ("protein_bert_base", "ESM1_T6", dict(token_dropout=True), "token_dropout"),
     ("esm2_t33", "ESM1B", dict(), "not one of the architectures"),
 ])
 def test_checkpoint_flags_the_engine_does_not_implement_raise(tmp_path, arch, base, args, msg):
@@ -411,6 +408,45 @@ def test_checkpoint_flags_the_engine_does_not_implement_raise(tmp_path, arch, ba
     _args_pt(path, sd, cfg, arch, **args)
     with pytest.raises(ValueError, match=msg):
         weights.load_fair_esm_checkpoint(str(path), cfg)
+
+
+@pytest.mark.parametrize("arch,base,args,msg", [
+    ("roberta_large", "ESM1B", dict(emb_layer_norm_before=False), "going by the tensors"),
+    ("roberta_large", "ESM1B", dict(final_bias=False), "final_bias=False.*ignored"),
+    ("msa_transformer", "MSA1B", dict(final_bias=False), "final_bias=False.*ignored"),
+    ("msa_transformer", "MSA1B", dict(token_dropout=True), "MSATransformer never reads it"),
+    ("protein_bert_base", "ESM1_T6", dict(emb_layer_norm_before=True), "going by the tensors"),
+])
+def test_checkpoint_flags_fair_esm_never_reads_are_ignored_with_a_warning(tmp_path, arch, base, args, msg):
+    """released `args` are the internal training namespace; a leftover flag that fair-esm does not honour for the
+    architecture must not make the loader refuse a file the reference's loader accepts.  The tensors load unchanged."""
+    from protein_gibbs_sampler_amd import weights
+    cfg = weights.make_config(getattr(weights, base + "_CONFIG"), d_model=128, n_layers=2, d_ffn=256, max_positions=40,
+                              **({"max_msa_rows": 8} if base == "MSA1B" else {}))
+    sd = weights.synthetic_state_dict(cfg, seed=2)
+    path = tmp_path / "f.pt"
+    _args_pt(path, sd, cfg, arch, **args)
+    with pytest.warns(UserWarning, match=msg):
+        got, cfg2 = weights.load_fair_esm_checkpoint(str(path), cfg, return_config=True)
+    assert cfg2["token_dropout"] == cfg["token_dropout"]
+    for k, v in sd.items():
+        if k == "embed_tokens.weight" and cfg["token_dropout"]:
+            v = v.copy()
+            v[cfg["mask_idx"]] = 0                     # the zeroed <mask> row of token-dropout checkpoints (weights.py)
+        assert np.array_equal(got[k], v), k
+
+
+def test_checkpoint_args_strip_one_prefix_per_architecture():
+    """fair-esm strips `encoder_` for roberta_large / msa_transformer and `decoder_` for protein_bert_base -- never both; a
+    leftover key with the other prefix must not shadow the real one by dict order."""
+    from protein_gibbs_sampler_amd import weights
+    a = weights.checkpoint_args({"args": {"arch": "roberta_large", "decoder_embed_dim": 999, "encoder_embed_dim": 1280, "layers": 3,
+                                          "encoder_layers": 33}})
+    assert a["embed_dim"] == 1280 and a["layers"] == 33 and a["decoder_embed_dim"] == 999
+    b = weights.checkpoint_args({"args": {"arch": "protein_bert_base", "encoder_embed_dim": 999, "decoder_embed_dim": 768}})
+    assert b["embed_dim"] == 768 and b["encoder_embed_dim"] == 999
+    c = weights.checkpoint_args({"args": {"arch": "msa_transformer", "encoder_ffn_embed_dim": 3072, "decoder_ffn_embed_dim": 1}})
+    assert c["ffn_embed_dim"] == 3072
 
 
 def test_checkpoint_without_embedding_layernorm_is_named(tmp_path):

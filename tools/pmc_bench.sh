@@ -8,7 +8,7 @@ P3="TCC_HIT TCC_MISS TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY GRBM_GUI_ACTIVE G
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmcb_${TAG}_$i -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-strict --no-msa --no-fp16 --no-host-entry --layers 3 "$@" > /tmp/pmcb_run.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmcb_${TAG}_$i -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-shard-proxy --no-roofline --no-strict --no-msa --no-fp16 --no-host-entry --layers 3 "$@" > /tmp/pmcb_run.log 2>&1
   python - "$i" "$TAG" "$KSUB" <<'PY'
 import csv, glob, sys, collections
 i, tag, ksub = sys.argv[1:4]

@@ -1,46 +1,122 @@
 #!/bin/bash
-# HBM traffic per kernel from PMC counters (separate --pmc passes, as the MI355X guide prescribes), run on the GPU box:
+# Fabric (L2 <-> Infinity Cache / HBM) traffic per kernel from PMC counters, separate --pmc passes as the MI355X guide prescribes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass), run on the GPU box:
 #   tools/pmc_traffic.sh TAG   -> gpurun_out/traffic_TAG.json
-# FETCH_SIZE / WRITE_SIZE are reported in KiB-like units and are mis-scaled on gfx950 (guide: FETCH_SIZE reads 1/2 of a wide
-# coalesced stream); both are CALIBRATED here on layernorm_bf16_kernel, whose traffic is known exactly
-# (reads M*d*4 bytes, writes M*d*2 bytes), and the same factors are applied to the other kernels.
+# FETCH_SIZE / WRITE_SIZE are mis-scaled on gfx950 (guide: FETCH_SIZE counts a wide coalesced stream's 128-B requests at 64 B;
+# WRITE_SIZE = (WRREQ - WRREQ_64B) * 32 + WRREQ_64B * 64 knows no 128-B request either), so both are CALIBRATED on kernels whose
+# traffic is known exactly -- and since round 6 the write side separately per store class (one LayerNorm-derived
+# factor had fc1 "writing" 577 MB of a 676 MB output):
+#   reads            layernorm_bf16_kernel        reads  M*d*4
+#   16-bit stores    layernorm_bf16_kernel        writes M*d*2          (LayerNorm rows, bf16 GEMM epilogues, attention context)
+#   fp32 stores      embed_ln_kernel              writes M*d*4 (+ M*d*2 of 16-bit rows, priced with the factor above)
+#                                                                       (residual GEMM epilogues)
+# Two further passes read the 32-byte-unit DRAM counters (TCC_EA0_RDREQ_DRAM_32B / TCC_EA0_WRREQ_WRITE_DRAM_32B: bytes = 32 x count,
+# no calibration) beside the request counters they refine; the JSON carries both views.  Every kernel whose MEASURED bytes fall
+# below its ALGORITHMIC bytes (operands read once, outputs written once) is flagged: a calibration that says so is wrong.
 TAG=${1:-r01}; ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/traf_${TAG}_$C -o p -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-strict --no-fp16 --no-msa --no-host-entry --layers 3 > /tmp/traf_run.log 2>&1
+BENCH="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-strict --no-fp16 --no-msa --no-host-entry --no-shard-proxy --layers 3"
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+  i=$((i+1))
+  rm -rf /tmp/traf_${TAG}_$i
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/traf_${TAG}_$i -o p -- $BENCH > /tmp/traf_run_$i.log 2>&1 || tail -3 /tmp/traf_run_$i.log
 done
 mkdir -p $ROOT/gpurun_out
 python - "$TAG" "$ROOT" <<'PY'
 import csv, glob, json, sys, collections
 tag, root = sys.argv[1:3]
-raw = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("/tmp/traf_%s_%s/**/*counter_collection.csv" % (tag, c), recursive=True)
-    agg = collections.defaultdict(lambda: [0.0, 0])
+raw = collections.defaultdict(dict)          # counter -> kernel -> (mean per launch, launches)
+for i in (1, 2, 3, 4):
+    f = glob.glob("/tmp/traf_%s_%d/**/*counter_collection.csv" % (tag, i), recursive=True)
+    if not f:
+        print("pass %d: no counter csv" % i); continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for row in csv.DictReader(open(f[0])):
-        if row["Counter_Name"] != c:
-            continue
         k = row["Kernel_Name"].split("(")[0]
-        agg[k][0] += float(row["Counter_Value"]); agg[k][1] += 1
-    raw[c] = {k: (v[0] / v[1], v[1]) for k, v in agg.items()}
-M, d = 66048, 1280
-ln = [k for k in raw["FETCH_SIZE"] if "layernorm_bf16" in k][0]
-f_scale = (M * d * 4) / raw["FETCH_SIZE"][ln][0]      # bytes per counter unit, read side
-w_scale = (M * d * 2) / raw["WRITE_SIZE"][ln][0]      # write side
-out = {"calibration": {"kernel": ln, "bytes_per_FETCH_SIZE_unit": f_scale, "bytes_per_WRITE_SIZE_unit": w_scale,
-                       "known_read_bytes": M * d * 4, "known_write_bytes": M * d * 2}, "kernels": {}}
-for k in raw["FETCH_SIZE"]:
-    fr, n = raw["FETCH_SIZE"][k]
-    wr = raw["WRITE_SIZE"].get(k, (0.0, 0))[0]
-    out["kernels"][k] = {"launches": n, "read_MB_per_launch": fr * f_scale / 1e6, "write_MB_per_launch": wr * w_scale / 1e6,
-                         "raw_FETCH_SIZE": fr, "raw_WRITE_SIZE": wr}
+        a = agg[row["Counter_Name"]][k]
+        a[0] += float(row["Counter_Value"]); a[1] += 1
+    for c, ks in agg.items():
+        raw[c] = {k: (v[0] / v[1], v[1]) for k, v in ks.items()}
+M, d, f = 66048, 1280, 5120
+def one(pat, c):
+    ks = [k for k in raw.get(c, {}) if pat in k]
+    return raw[c][ks[0]][0] if ks else None
+ln = [k for k in raw["FETCH_SIZE"] if "layernorm_bf16_kernel" in k][0]
+emb = [k for k in raw["FETCH_SIZE"] if "embed_ln_kernel" in k]
+f_scale = (M * d * 4) / raw["FETCH_SIZE"][ln][0]                 # bytes per FETCH_SIZE unit
+w16 = (M * d * 2) / raw["WRITE_SIZE"][ln][0]                     # bytes per WRITE_SIZE unit, 16-bit row stores
+w32 = None
+if emb and raw["WRITE_SIZE"].get(emb[0]):
+    # embed_ln writes the fp32 residual rows (M*d*4) and the first LayerNorm's 16-bit rows (M*d*2): if the two store classes were
+    # counted alike, its WRITE_SIZE would be 3x LayerNorm's; what is left after the 16-bit share prices the fp32 stores
+    w_emb = raw["WRITE_SIZE"][emb[0]][0]
+    fp32_units = w_emb - (M * d * 2) / w16
+    if fp32_units > 0:
+        w32 = (M * d * 4) / fp32_units
+out = {"calibration": {"read": {"kernel": ln, "bytes_per_FETCH_SIZE_unit": f_scale, "known_read_bytes": M * d * 4},
+                       "write_16bit_stores": {"kernel": ln, "bytes_per_WRITE_SIZE_unit": w16, "known_write_bytes": M * d * 2},
+                       "write_fp32_stores": {"kernel": emb[0] if emb else None, "bytes_per_WRITE_SIZE_unit": w32,
+                                             "known_write_bytes": M * d * 4, "beside": "M*d*2 of 16-bit rows priced with the 16-bit factor"},
+                       # kept for readers of the r01-r05 files
+                       "kernel": ln, "bytes_per_FETCH_SIZE_unit": f_scale, "bytes_per_WRITE_SIZE_unit": w16,
+                       "known_read_bytes": M * d * 4, "known_write_bytes": M * d * 2},
+       "kernels": {}}
 # projection -> kernel name of this build (bench.py's GEMM_CLASS_PATTERNS; the JSON's table wins there)
 pats = (("gemm_qkv", "gemm_bf16_w16_kernel<0"), ("gemm_fc1", "gemm_bf16_w16_kernel<1"),
         ("gemm_out", "gemm_bf16_pp_kernel<2, 0, 4"), ("gemm_fc2", "gemm_bf16_pp_kernel<2, 0, 2"))
-out["classes"] = {c: next((k for k in out["kernels"] if p in k), None) for c, p in pats}
-out["command"] = "bench.py --steps 1 --warmup 0 --layers 3 (config 2 shapes: 256 chains x T=258), one rocprofv3 --pmc pass per counter"
+classes = {c: next((k for k in raw["FETCH_SIZE"] if p in k), None) for c, p in pats}
+# algorithmic bytes (read, write) and the store class of the kernels whose shapes are known here
+alg = {"gemm_qkv": (M * d * 2 + 3 * d * d * 2, M * 3 * d * 2, "16"), "gemm_fc1": (M * d * 2 + f * d * 2, M * f * 2, "16"),
+       "gemm_out": (M * d * 2 + d * d * 2 + M * d * 4, M * d * 4, "32"), "gemm_fc2": (M * f * 2 + d * f * 2 + M * d * 4, M * d * 4, "32")}
+by_kernel = {v: k for k, v in classes.items() if v}
+for k in raw["FETCH_SIZE"]:
+    if "layernorm_bf16_kernel" in k and k not in by_kernel: by_kernel[k] = "layernorm"
+    if "attention_kernel" in k and k not in by_kernel: by_kernel[k] = "attention"
+    if "embed_ln_kernel" in k and k not in by_kernel: by_kernel[k] = "embed_ln"
+alg.update({"layernorm": (M * d * 4, M * d * 2, "16"), "attention": (M * 3 * d * 2, M * d * 2, "16"),
+            "embed_ln": (None, M * d * 6, "mixed")})
+flags = []
+for k in raw["FETCH_SIZE"]:
+    fr, n = raw["FETCH_SIZE"][k]
+    wr = raw["WRITE_SIZE"].get(k, (0.0, 0))[0]
+    cls = by_kernel.get(k)
+    store = alg[cls][2] if cls else "16"
+    if store == "32" and w32:
+        w_bytes, w_how = wr * w32, "fp32-store factor"
+    elif store == "mixed" and w32:
+        w_bytes, w_how = M * d * 2 + (wr - (M * d * 2) / w16) * w32, "16-bit share at the 16-bit factor, rest at the fp32-store factor"
+    else:
+        w_bytes, w_how = wr * w16, "16-bit-store factor"
+    e = {"launches": n, "read_MB_per_launch": fr * f_scale / 1e6, "write_MB_per_launch": w_bytes / 1e6, "write_calibration": w_how,
+         "raw_FETCH_SIZE": fr, "raw_WRITE_SIZE": wr}
+    rd32 = raw.get("TCC_EA0_RDREQ_DRAM_32B_sum", {}).get(k)
+    wr32 = raw.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", {}).get(k)
+    if rd32: e["dram_read_MB_per_launch_32B_units"] = rd32[0] * 32 / 1e6
+    if wr32: e["dram_write_MB_per_launch_32B_units"] = wr32[0] * 32 / 1e6
+    for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"):
+        if raw.get(c, {}).get(k): e["raw_" + c] = raw[c][k][0]
+    if cls:
+        a_rd, a_wr, _ = alg[cls]
+        e["class"] = cls
+        e["algorithmic_read_MB"] = None if a_rd is None else a_rd / 1e6
+        e["algorithmic_write_MB"] = a_wr / 1e6
+        if a_rd is not None and e["read_MB_per_launch"] < 0.98 * a_rd / 1e6:
+            flags.append("%s (%s): measured read %.0f MB < algorithmic %.0f MB" % (cls, k[:60], e["read_MB_per_launch"], a_rd / 1e6))
+        if e["write_MB_per_launch"] < 0.98 * a_wr / 1e6:
+            flags.append("%s (%s): measured write %.0f MB < algorithmic %.0f MB" % (cls, k[:60], e["write_MB_per_launch"], a_wr / 1e6))
+    out["kernels"][k] = e
+out["classes"] = classes
+out["measured_below_algorithmic"] = flags
+out["command"] = ("bench.py --steps 1 --warmup 0 --layers 3 --no-shard-proxy (config 2 shapes: 256 chains x T=258), one rocprofv3 --pmc pass per "
+                  "counter group: FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_DRAM_32B + request sizes | TCC_EA0_WRREQ_WRITE_DRAM_32B + request sizes")
 json.dump(out, open("%s/gpurun_out/traffic_%s.json" % (root, tag), "w"), indent=1)
+print("%-62s %3s %9s %9s | %9s %9s | %9s %9s" % ("kernel", "n", "read MB", "write MB", "alg read", "alg write", "rd 32B-u", "wr 32B-u"))
 for k, v in out["kernels"].items():
-    print("%-70s n=%3d read %8.1f MB write %8.1f MB" % (k[:70], v["launches"], v["read_MB_per_launch"], v["write_MB_per_launch"]))
-print("calibration:", out["calibration"])
+    print("%-62s %3d %9.1f %9.1f | %9s %9s | %9s %9s" % (k[:62], v["launches"], v["read_MB_per_launch"], v["write_MB_per_launch"],
+          "%.1f" % v["algorithmic_read_MB"] if v.get("algorithmic_read_MB") else "-", "%.1f" % v["algorithmic_write_MB"] if v.get("algorithmic_write_MB") else "-",
+          "%.1f" % v["dram_read_MB_per_launch_32B_units"] if "dram_read_MB_per_launch_32B_units" in v else "-",
+          "%.1f" % v["dram_write_MB_per_launch_32B_units"] if "dram_write_MB_per_launch_32B_units" in v else "-"))
+print("calibration: read %.1f B/unit (LayerNorm), write 16-bit stores %.1f B/unit (LayerNorm), fp32 stores %s B/unit (embed_ln)" % (f_scale, w16, "%.1f" % w32 if w32 else "n/a"))
+print("MEASURED BELOW ALGORITHMIC:", flags if flags else "none")
 PY

@@ -10,7 +10,7 @@ tail -3 $OUT/pytest_gpu.log
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/bench_default.json; echo
 export TMPDIR=/tmp
-(cd /tmp && rm -rf /tmp/prof_$TAG && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strict --no-msa > /tmp/prof_$TAG.log 2>&1)
+(cd /tmp && rm -rf /tmp/prof_$TAG && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-shard-proxy --no-strict --no-msa > /tmp/prof_$TAG.log 2>&1)
 cp $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) $OUT/esm1b_cfg2_kernel_stats.csv 2>/dev/null
 head -12 $OUT/esm1b_cfg2_kernel_stats.csv | cut -c1-70,150-230
 bash tools/pmc_traffic.sh $TAG > $OUT/pmc_traffic.log 2>&1; cp gpurun_out/traffic_$TAG.json $OUT/hbm_traffic_pmc.json 2>/dev/null; tail -4 $OUT/pmc_traffic.log
