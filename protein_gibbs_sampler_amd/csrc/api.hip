@@ -599,14 +599,14 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
     bf16_t* bout = (bf16_t*)t.get((size_t)Mp * N * 2);
     if (!bout) return fail(PG_ERR_HIP, "hipMalloc failed");
     if ((rc = DBG_OPS(launch_gemm_bf16, nullptr, bx, bw, db, bout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
-                      epi == 4 ? EPI_BF16_GELU : EPI_BF16, nullptr, 0))) return rc;
+                      epi == 4 ? EPI_BF16_GELU : EPI_BF16, nullptr, 0, M))) return rc;
     if ((rc = DBG_OPS(launch_bf16_to_f32, nullptr, bout, dout, (int64_t)M * N))) return rc;
   } else {
     // the residual variant gets split-K scratch, as the engine gives its fc2 GEMMs (taken for deep K and few tiles)
     const size_t ws_bytes = epi == 2 ? (size_t)5 * Mp * N * 4 : 0;
     float* ws = ws_bytes && ws_bytes <= ((size_t)1 << 30) ? (float*)t.get(ws_bytes) : nullptr;
     if ((rc = DBG_OPS(launch_gemm_bf16, nullptr, bx, bw, db, dout, M <= 256 ? round_up(M, 16) : Mp, N, K, K, K, N,
-                      epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32), ws, ws ? ws_bytes : 0))) return rc;
+                      epi == 2 ? EPI_F32_RESID : (epi ? EPI_F32_GELU : EPI_F32), ws, ws ? ws_bytes : 0, M))) return rc;
   }
   PG_HIP(hipDeviceSynchronize());
   PG_HIP(hipMemcpy(out, dout, (size_t)M * N * 4, hipMemcpyDeviceToHost));

@@ -16,6 +16,8 @@
 //     lane) comes straight out of the row-major V tile through gfx950's transposing LDS read ds_read_b64_tr_b16 -- no
 //     transposition pass when the tile is staged (that pass and its 4-byte LDS writes were 16 % of the kernel).
 //   * O^T = V^T.P^T, so a lane ends with 4 consecutive d for one query -> 8-byte row-major stores.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 PG_OPS_BEGIN
@@ -43,11 +45,16 @@ __device__ unsigned long long* pg_att_prof;      // [workgroup][wave][8 slots][8
 
 // BIASKV: ESM-1's extra bias_k / bias_v key (a template parameter: the extra staging branch and the runtime key count cost the
 // config-2 kernel 8 % when they were runtime conditions)
-template <int MAXKB, bool PADMASK, bool BIASKV = false>
+// SPLIT (round 6): the grid's LAST workgroups each take 1 / split of one (sequence, head) pair's query blocks instead of a whole pair
+// -- workgroups [0, split_from) whole pairs, workgroup split_from + u the blocks part, part + split, ... (part = u % split) of pair
+// split_from + u / split -- so that the partial last round of a launch (a 32-chain shard: 640 pairs on 512 resident workgroups =
+// one full round + a quarter-full one that takes as long) becomes short workgroups that fill the chip.  A query block's arithmetic
+// does not depend on which workgroup runs it: same bits.  The plain launch (SPLIT = false) is the kernel of rounds 1-5, unchanged.
+template <int MAXKB, bool PADMASK, bool BIASKV = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, int T,
                                                        int H, int ld_qkv_, int ld_ctx_, int k_off, int v_off,
                                                        SeqLayout sl, const int32_t* __restrict__ key_tok, int pad_idx,
-                                                       const bf16_t* __restrict__ bias_kv) {
+                                                       const bf16_t* __restrict__ bias_kv, int split_from = 0, int split = 1) {
   __shared__ __attribute__((aligned(16))) char smem[2 * MAXKB * 16 * 128 + (PADMASK ? MAXKB * 16 : 0)];
   char* Ks = smem;
   char* Vs = smem + MAXKB * 16 * 128;          // V rows, same layout as K: row*128 + ((chunk ^ (row & 7)) << 4)
@@ -57,7 +64,14 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
   PG_T(7, 0);
   // sequence `seq` = token rows row0 + t*row_step (ESM: contiguous rows of chain b; MSA column attention: the R rows
   // of one column, C token-rows apart)
-  const int seq = blockIdx.x / H, h = blockIdx.x % H;
+  int pair = blockIdx.x, qb_first = wave, qb_step = 4;
+  if (SPLIT && (int)blockIdx.x >= split_from) {
+    const int u = blockIdx.x - split_from;
+    pair = split_from + u / split;
+    qb_first = u % split + split * wave;                     // blocks part, part + split, ... dealt to the waves in turn
+    qb_step = 4 * split;
+  }
+  const int seq = pair / H, h = pair % H;
   const size_t row0 = (size_t)(seq / sl.inner_count) * sl.outer_rows + (size_t)(seq % sl.inner_count) * sl.inner_rows;
   const size_t ld_qkv = (size_t)ld_qkv_ * sl.row_step, ld_ctx = (size_t)ld_ctx_ * sl.row_step;
   const bf16_t* base = qkv + row0 * ld_qkv_ + h * 64;
@@ -118,9 +132,9 @@ __global__ __launch_bounds__(256, (MAXKB <= 18 ? 2 : 1)) void attention_kernel(c
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) dst[kk] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + kk * 32 + fq * 8);
   };
-  if (wave < nqb) load_q(wave, qf);
-  for (int qb = wave; qb < nqb; qb += 4) {
-    if (qb + 4 < nqb) load_q(qb + 4, qn);
+  if (qb_first < nqb) load_q(qb_first, qf);
+  for (int qb = qb_first; qb < nqb; qb += qb_step) {
+    if (qb + qb_step < nqb) load_q(qb + qb_step, qn);
     PG_T(qb >> 2, 0);
 
     // S^T blocks: st[kb][r] = S[query fr][key kb*16 + fq*4 + r]
@@ -461,11 +475,33 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
   if (n_seq == 0) return 0;
   if (n_seq * H > 0x7fffffff) return fail(1, "attention: too many sequences");
   dim3 grid((unsigned)(n_seq * H)), block(256);
+  // Round 6: split the pairs of a partial last round (see attention_kernel).  Whole-sequence kernels for chains (row_step 1) of at
+  // least four query blocks, without <pad> mask / bias key (the Gibbs path).  Resident workgroups: two per CU up to 20 key blocks
+  // (2 x 80 KB of LDS), one beyond.  PGIBBS_ATTN_SPLIT=0 switches it off.
+  static const int split_on = [] { const char* e = getenv("PGIBBS_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+  static const int n_cu = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+  int split_from = 0, split = 1;
+  if (split_on && !key_tok && !bias_kv && sl.row_step == 1 && T >= 64 && T <= 576) {
+    const int kb = (((T + 15) / 16) + 1) & ~1;            // the rung of the ladder below: key blocks, even
+    const long pairs = n_seq * H, slots = (long)n_cu * (kb <= 20 ? 2 : 1);
+    const long rem = pairs % slots;
+    const int nqb = (T + 15) / 16;
+    int sp = rem ? (int)(slots / rem) : 1;
+    if (sp > 4) sp = 4;
+    if (sp > nqb / 4) sp = nqb / 4;            // every part keeps at least one block per wave
+    if (sp >= 2) {
+      split = sp;
+      split_from = (int)(pairs - rem);
+      grid = dim3((unsigned)(split_from + rem * sp));
+    }
+  }
+#define PG_ATT_SPLIT_LAUNCH(KB) hipLaunchKernelGGL((attention_kernel<KB, false, false, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv, split_from, split)
 #define PG_ATT(KB)                                                                                             \
   else if (Tk <= KB * 16) {                                                                                    \
     if (bias_kv && key_tok) hipLaunchKernelGGL((attention_kernel<KB, true, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
     else if (bias_kv) hipLaunchKernelGGL((attention_kernel<KB, false, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
     else if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else if (split > 1) PG_ATT_SPLIT_LAUNCH(KB);                                                               \
     else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
   }
   const int Tk = T + (bias_kv ? 1 : 0);          // keys: the T tokens + ESM-1's bias_k / bias_v
@@ -476,12 +512,14 @@ int launch_attention_seq_bf16(hipStream_t s, const bf16_t* qkv, bf16_t* ctx, int
 #define PG_ATT_PLAIN(KB)                                                                                       \
   else if (fine_ladder && !bias_kv && Tk <= KB * 16) {                                                         \
     if (key_tok) hipLaunchKernelGGL((attention_kernel<KB, true>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
+    else if (split > 1) PG_ATT_SPLIT_LAUNCH(KB);                                                               \
     else hipLaunchKernelGGL((attention_kernel<KB, false>), grid, block, 0, s, qkv, ctx, T, H, ld_qkv, ld_ctx, k_off, v_off, sl, key_tok, pad_idx, bias_kv); \
   }
   PG_ATT(2) PG_ATT(4) PG_ATT_PLAIN(6) PG_ATT(8) PG_ATT_PLAIN(10) PG_ATT(12) PG_ATT_PLAIN(14) PG_ATT_PLAIN(16) PG_ATT(18)
   PG_ATT_PLAIN(20) PG_ATT_PLAIN(22) PG_ATT(24) PG_ATT_PLAIN(26) PG_ATT_PLAIN(28) PG_ATT(30) PG_ATT_PLAIN(32) PG_ATT_PLAIN(34) PG_ATT(36)
 #undef PG_ATT_PLAIN
 #undef PG_ATT
+#undef PG_ATT_SPLIT_LAUNCH
   else {
     const int n_qchunk = (T + 63) / 64;
     if (n_seq * H * n_qchunk > 0x7fffffff) return fail(1, "attention: too many sequences");

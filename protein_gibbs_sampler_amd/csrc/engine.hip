@@ -561,15 +561,15 @@ per_layer:
     if (ln_in_gemm) {
       if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, CTX, L.out.w, L.out.b, X, Mi, d, d, d, d, d, EPI_F32_RESID); }))) return rc;
       if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_ln_skinny, stream, X, d, L.ln2.g, L.ln2.b, eps, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, f, EPI_BF16_GELU); }))) return rc;
-      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes, (int)M); }))) return rc;
       continue;
     }
     if ((rc = resid_gemm_ln(CTX, L.out, X, Mi, M, d, L.ln2, Hh, nullptr, 0, PC_GEMM_OUT))) return rc;   // x += out_proj(ctx); h = LN2(x)
-    if ((rc = timed(PC_GEMM_FC1, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = timed(PC_GEMM_FC1, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU, nullptr, 0, (int)M); }))) return rc;
     if (l + 1 < cfg.n_layers) {                                                                    // x += fc2(ffn); h = LN1 of the next layer
       if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, esm_layers[l + 1].ln1, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes, PC_GEMM_FC2))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM_FC2, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM_FC2, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes, (int)M); }))) return rc;
     }
   }
   return PG_OK;
@@ -581,7 +581,7 @@ per_layer:
 int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
                           float* ws, size_t ws_bytes, int prof_class, int colmajor_R, int colmajor_C) {
   const int d = W.N, K = W.K;
-  int rc = timed(prof_class, [&] { return OPS(launch_gemm_bf16, stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes); });
+  int rc = timed(prof_class, [&] { return OPS(launch_gemm_bf16, stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes, (int)M_real); });
   if (rc) return rc;
   return timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps, false, colmajor_R, colmajor_C); });
 }
@@ -843,11 +843,11 @@ int Engine::msa_trunk(const int32_t* d_tok, int B, int R, int C, const int32_t* 
     }
     if ((rc = resid_gemm_ln(CTX, L.col_out, X, Mi, M, d, L.ln_ffn, Hh, nullptr, 0, PC_GEMM_OUT))) return rc;                 // x += col_out(ctx); h = LN_ffn(x)
     // feed forward
-    if ((rc = timed(PC_GEMM_FC1, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU); }))) return rc;
+    if ((rc = timed(PC_GEMM_FC1, [&] { return OPS(launch_gemm_bf16, stream, Hh, L.fc1.w, L.fc1.b, FFN, Mi, f, d, d, d, f, EPI_BF16_GELU, nullptr, 0, (int)M); }))) return rc;
     if (l + 1 < cfg.n_layers) {                                                                      // x += fc2(ffn); h = LN_row of the next layer
       if ((rc = resid_gemm_ln(FFN, L.fc2, X, Mi, M, f, msa_layers[l + 1].ln_row, Hh, splitk_ws(Mi, d, batch_rows), splitk.bytes, PC_GEMM_FC2))) return rc;
     } else {
-      if ((rc = timed(PC_GEMM_FC2, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes); }))) return rc;
+      if ((rc = timed(PC_GEMM_FC2, [&] { return OPS(launch_gemm_bf16, stream, FFN, L.fc2.w, L.fc2.b, X, Mi, d, f, f, f, d, EPI_F32_RESID, splitk_ws(Mi, d, batch_rows), splitk.bytes, (int)M); }))) return rc;
     }
   }
   return PG_OK;

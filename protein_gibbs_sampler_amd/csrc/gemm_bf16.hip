@@ -722,13 +722,48 @@ void gemm_big_geometry(int M, int N, int K, int* m_main_panels, int* tail_rows) 
 // the 8-wave ping-pong kernel for the fp32 outputs (the 16-wave kernel loses 3-4 % on the residual read-modify-write);
 // PGIBBS_GEMM_BIG=pp / w16 forces one kernel for the plain epilogues.  M, N multiples of 256, K a multiple of 64, K >= 128.
 int launch_gemm_big(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K, int ldx,
-                    int ldw, int ldo, int epi) {
+                    int ldw, int ldo, int epi, int m_live) {
   if (M % 256 || N % 256 || K % 64 || K < 128 || M < 256) return fail(1, "gemm_big: shape");
   static const int big = [] { const char* e = getenv("PGIBBS_GEMM_BIG"); return !e ? -1 : (e[0] == 'w' ? 16 : 0); }();
   const BigGeom geo = big_geometry(M, N, K);
   const int m_main = geo.m_main, tail_rows = geo.tail_rows;
   const bool bf16out = epi == EPI_BF16 || epi == EPI_BF16_GELU;
   const bool use16 = big == 16 || (big == -1 && bf16out);
+  static const int n_cu_l = [] { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
+  // Round 6: the tile-height ladder (gemm_ladder.hip; heights 160 ... 240 in steps of 16 rows).  Built for VERDICT r05's tile-count
+  // argument -- a partial last round of tiles costs a whole one, and N = 1280 (five tiles per row panel) quantises badly for a
+  // 1/8 ... 1/2 shard of config 3 -- and MEASURED (profiles/r06_ladder_bench.txt, r06_shard_proxy_ladder_ab.txt): every height
+  // takes the same time to within 3 % at every shard size (a 32-chain shard's fc2: 165 tiles of 256 rows 128.8 us, 220 of 192
+  // 127.0, 240 of 176 133.6, 190 of 224 128.7), bit-identical results.  These launches run at a fixed aggregate L2 -> LDS feed of
+  // ~8 TB/s whatever the tiling (bytes staged / time: 6.8 ... 8.5 TB/s from the 32-chain shard to the full batch), so idle CUs in a
+  // partial round are not lost throughput and a smaller tile only raises the bytes staged per FLOP.  OFF by default;
+  // PGIBBS_GEMM_LADDER=1 prices the candidates in rounds x height (the model that does not hold), =h forces height h where the
+  // epilogue has it (the A/B switch of tests/test_gpu_kernels.py and tools/ladder_bench.py).
+  static const int ladder = [] { const char* e = getenv("PGIBBS_GEMM_LADDER"); return e ? atoi(e) : 0; }();
+  const int live = m_live > 0 && m_live <= M ? m_live : M;
+  const int tiles_n_l = N / 256;
+  double cost_old;
+  {
+    const long t256 = (long)(M / 256) * tiles_n_l;
+    cost_old = tail_rows ? (double)((long)m_main * tiles_n_l / n_cu_l) + 0.15 : (double)((t256 + n_cu_l - 1) / n_cu_l);
+    static const int t192e = [] { const char* e = getenv("PGIBBS_GEMM_T192"); return e ? atoi(e) : 1; }();
+    if (t192e && epi == EPI_F32_RESID) {
+      const int m192 = M / 192, rest = M - m192 * 192;
+      const double r192 = 0.75 * (double)(((long)m192 * tiles_n_l + n_cu_l - 1) / n_cu_l) + (rest ? 0.2 : 0.0);
+      if (r192 <= 0.9 * cost_old) cost_old = r192;
+    }
+  }
+  if (ladder && (epi == EPI_F32_RESID || epi == EPI_BF16_GELU)) {
+    int best_h = 0;
+    double best = 0.95 * cost_old;
+    for (int h = 240; h >= 160; h -= 16) {
+      if (!gemm_ladder_has(epi, h) || (ladder > 1 && ladder != h)) continue;
+      const long tiles = (long)((live + h - 1) / h) * tiles_n_l;
+      const double c = (double)((tiles + n_cu_l - 1) / n_cu_l) * h / 256.0;
+      if (ladder == h || c < best - 1e-9) { best = c; best_h = h; if (ladder == h) break; }
+    }
+    if (best_h) return launch_gemm_ladder(s, X, W, bias, out, live, M, best_h, N, K, ldx, ldw, ldo, epi);
+  }
   if (use16) return launch_gemm_w16(s, X, W, bias, out, m_main * 256, N, K, ldx, ldw, ldo, epi, 0, tail_rows);
   // Residual GEMMs of mid-size batches: 256-row tiles quantise badly (a 32-chain shard's out-projection / fc2: 165 tiles on 256 CUs,
   // a 64-chain one: 325 = two rounds of which the second is a quarter full).  192 x 256 tiles (same kernel, 6 instead of 8 row
@@ -1092,9 +1127,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int launch_gemm_bf16(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N, int K,
-                     int ldx, int ldw, int ldo, int epi, float* ws, size_t ws_bytes) {
+                     int ldx, int ldw, int ldo, int epi, float* ws, size_t ws_bytes, int m_live) {
   static const int variant = [] { const char* e = getenv("PGIBBS_GEMM"); return e ? atoi(e) : 2; }();
-  return launch_gemm_bf16_variant(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant, ws, ws_bytes);
+  return launch_gemm_bf16_variant(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, variant, ws, ws_bytes, m_live);
 }
 
 #ifndef PG_F16
@@ -1118,7 +1153,7 @@ int launch_gemm_split3(hipStream_t s, const bf16_t* X3, const bf16_t* W3, const 
 #endif  // !PG_F16
 
 int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, const float* bias, void* out, int M, int N,
-                             int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws, size_t ws_bytes) {
+                             int K, int ldx, int ldw, int ldo, int epi, int variant, float* ws, size_t ws_bytes, int m_live) {
   // Dispatch by how many tiles each kernel would put on the 256 CUs (times in us, tools/gemm_mid_bench.py, N=1280 K=1280):
   //   M =    16    64   256  1024  4096  16384
   //   skinny 4.3   8.7  26.4                       one workgroup per 16 output features, weights streamed once
@@ -1184,7 +1219,7 @@ int launch_gemm_bf16_variant(hipStream_t s, const bf16_t* X, const bf16_t* W, co
     if (ok256) return launch_cfg<256, 256, 128, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
     if (ok128) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   }
-  if (ok256 && t256 >= 128) return launch_gemm_big(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
+  if (ok256 && t256 >= 128) return launch_gemm_big(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi, m_live);
   if (ok128 && (t128 >= 200 || !(M % 64 == 0))) return launch_cfg<128, 128, 64, 64>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
   return launch_cfg<64, 64, 32, 32>(s, X, W, bias, out, M, N, K, ldx, ldw, ldo, epi);
 }

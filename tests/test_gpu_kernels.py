@@ -121,6 +121,43 @@ def test_attention(B, T, H):
     assert np.abs(ctx - ref).mean() < 3e-3
 
 
+_ATT_SPLIT_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import _lib
+outs = []
+for (B, T, H, prec) in [(3, 258, 2, 0), (33, 258, 20, 0), (1, 64, 1, 0), (7, 130, 3, 0), (40, 100, 20, 0), (2, 513, 2, 0), (5, 330, 4, 2), (27, 258, 20, 2)]:
+    rng = np.random.default_rng(B * 1000 + T)
+    d = H * 64
+    qkv = rng.standard_normal((B, T, 3 * d), dtype=np.float32)
+    qkv[..., :d] *= 0.35
+    ctx = np.empty((B, T, d), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_attention(0, prec, _lib.ptr(qkv), _lib.ptr(ctx), B, T, H))
+    outs.append(ctx)
+np.savez(sys.argv[1], *outs)
+"""
+
+
+def test_attention_split_of_the_last_round_is_bit_identical(tmp_path):
+    """Round 6: the (sequence, head) pairs of a launch's partial last round are split over 2-4 workgroups by query blocks
+    (attention_kernel<.., SPLIT>: 640 pairs of a 32-chain shard = 512 whole + 128 x 4 quarter workgroups).  A query block's
+    arithmetic does not depend on the workgroup that runs it: PGIBBS_ATTN_SPLIT=1 (default) and =0 give the same bits -- few pairs
+    (everything split), more pairs than resident workgroups (33 x 20: 512 whole + 148 x 3), both operand flavours."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for sw in ("1", "0"):
+        f = str(tmp_path / ("att_%s.npz" % sw))
+        p = subprocess.run([sys.executable, "-c", _ATT_SPLIT_CHILD % root, f], capture_output=True, text=True,
+                           env=dict(os.environ, PGIBBS_ATTN_SPLIT=sw), timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[sw] = np.load(f)
+    assert len(res["0"].files) == 8
+    for k in res["0"].files:
+        assert np.isfinite(res["0"][k]).all() and np.abs(res["0"][k]).max() > 0
+        assert (res["1"][k].view(np.uint32) == res["0"][k].view(np.uint32)).all(), k
+
+
 _T192_CHILD = """
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -138,6 +175,51 @@ for (M, N, K, prec) in [(8448, 1280, 1280, _lib.PG_PREC_BF16), (8448, 1280, 5120
     outs.append(out[::7].copy())
 np.savez(sys.argv[1], *outs)
 """
+
+
+_LADDER_CHILD = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from protein_gibbs_sampler_amd import _lib
+outs = []
+# (live rows M, N, K, epilogue 2 = residual / 4 = bias + GELU with 16-bit output, precision); M is padded to 256 inside: the cases
+# cover an exact fit (8448 = 48 x 176), a shifted last row panel (M_pad not a multiple of the height), live rows well below the padding,
+# the shortest K (two K-tiles), the deep K of fc2 (tile grouping 2) and the fp16-operand flavour
+for (M, N, K, epi, prec) in [(8256, 1280, 1280, 2, _lib.PG_PREC_BF16), (8256, 1280, 5120, 2, _lib.PG_PREC_BF16), (8256, 5120, 1280, 4, _lib.PG_PREC_BF16),
+                             (16512, 1280, 1280, 2, _lib.PG_PREC_BF16), (3300, 2560, 128, 2, _lib.PG_PREC_BF16), (3300, 2560, 320, 4, _lib.PG_PREC_BF16),
+                             (33024, 1280, 320, 2, _lib.PG_PREC_BF16), (8256, 1280, 1280, 2, _lib.PG_PREC_F16), (6000, 1536, 768, 4, _lib.PG_PREC_F16)]:
+    rng = np.random.default_rng(M + K + epi)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((N, K), dtype=np.float32) * np.float32(1.0 / np.sqrt(K))
+    b = rng.standard_normal(N, dtype=np.float32)
+    out = rng.standard_normal((M, N), dtype=np.float32)
+    _lib.check(_lib.lib().pg_dbg_gemm(0, prec, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), M, N, K, epi))
+    outs.append(np.concatenate([out[::5], out[-300:]]).copy())          # a sample of all rows + the whole last row panels
+np.savez(sys.argv[1], *outs)
+"""
+
+
+@pytest.mark.parametrize("height", [160, 176, 208, 224, 240])
+def test_tile_height_ladder_is_bit_identical_with_256_row_tiles(tmp_path, height):
+    """gemm_ladder.hip (round 6): the 8-wave kernel with (XJ0 + XJ1) x 16 token rows per tile, picked by launch_gemm_big when a
+    height between 160 and 240 rows needs fewer round-equivalents than 256- / 192-row tiles (a 32-chain shard's out-projection /
+    fc2: 235 tiles of 176 rows; its fc1: 740 tiles of 224).  PGIBBS_GEMM_LADDER=h forces height h wherever the epilogue has it
+    (residual: all five; fc1's GELU epilogue: 208, 224, 240 -- the others then run the default dispatch), =0 forbids the ladder:
+    equal bit for bit, incl. the row panels at the end (a last panel that would reach past the padded rows is shifted up and must
+    not add to the residual rows of its neighbour twice)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for sw in (str(height), "0"):
+        f = str(tmp_path / ("ladder_%s.npz" % sw))
+        p = subprocess.run([sys.executable, "-c", _LADDER_CHILD % root, f], capture_output=True, text=True,
+                           env=dict(os.environ, PGIBBS_GEMM_LADDER=sw, PGIBBS_GEMM_T192="0"), timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[sw] = np.load(f)
+    assert len(res["0"].files) == 9
+    for k in res["0"].files:
+        assert np.isfinite(res["0"][k]).all()
+        assert (res[str(height)][k] == res["0"][k]).all(), (height, k)
 
 
 def test_192_row_tiles_are_bit_identical_with_256_row_tiles(tmp_path):

@@ -31,8 +31,8 @@ lm.set_job_items(0)
 valid = list(range(4, 24))
 d, f, nl, V = cfg["d_model"], cfg["d_ffn"], cfg["n_layers"], cfg["vocab"]
 print("# few-chain sweep, ESM-1b 33 x 1280, %s operands; peak = 2500 TFLOP/s dense bf16; executed FLOPs (last layer pruned)" % args.precision)
-print("# %-6s %-4s %-6s %9s %8s %6s | %6s %6s %6s %6s %6s %6s | kernels: qkv ; out ; fc1 ; fc2" %
-      ("chains", "L", "rows", "ms/iter", "TFLOP/s", "frac", "gemm", "attn", "ln", "embed", "head", "sample"))
+print("# %-6s %-4s %-6s %9s %8s %6s | %6s %6s %6s %6s %6s %6s | %6s %6s %6s %6s | kernels: qkv ; out ; fc1 ; fc2" %
+      ("chains", "L", "rows", "ms/iter", "TFLOP/s", "frac", "gemm", "attn", "ln", "embed", "head", "sample", "qkv", "out", "fc1", "fc2"))
 for L in [int(v) for v in args.lengths.split(",")]:
     T, P = L + 2, max(1, int(L * 10 / 100))
     for B in [int(v) for v in args.chains.split(",")]:
@@ -56,6 +56,7 @@ for L in [int(v) for v in args.lengths.split(",")]:
         lm.prof_enable(True); lm.prof_reset(); run(2)
         cls = {c: lm.prof_get(c)[0] / 2 for c in ("gemm", "attention", "layernorm", "embed", "head", "sample")}
         kern = [lm.prof_get_kernels(c) or "-" for c in ("gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2")]
+        proj = [lm.prof_get(c)[0] / 2 for c in ("gemm_qkv", "gemm_out", "gemm_fc1", "gemm_fc2")]
         other = lm.prof_get_kernels("gemm_other")
         lm.prof_enable(False)
         M, S = B * T, B * P
@@ -63,6 +64,6 @@ for L in [int(v) for v in args.lengths.split(",")]:
         last = 2.0 * 3 * d * d * M + 2.0 * (d * d + 2 * d * f) * S
         fl = (nl - 1) * full + last + nl * 4.0 * T * d * M + (2.0 * d * d + 2.0 * V * d) * S
         tf = fl / (ms * 1e-3) / 1e12
-        print("  %-6d %-4d %-6d %9.3f %8.1f %6.3f | %6.3f %6.3f %6.3f %6.3f %6.3f %6.3f | %s%s" %
+        print("  %-6d %-4d %-6d %9.3f %8.1f %6.3f | %6.3f %6.3f %6.3f %6.3f %6.3f %6.3f | %6.3f %6.3f %6.3f %6.3f | %s%s" %
               (B, L, M, ms, tf, tf / 2500.0, cls["gemm"], cls["attention"], cls["layernorm"], cls["embed"], cls["head"], cls["sample"],
-               " ; ".join(kern), ("   [other: %s]" % other) if other else ""), flush=True)
+               proj[0], proj[1], proj[2], proj[3], " ; ".join(kern), ("   [other: %s]" % other) if other else ""), flush=True)
