@@ -120,8 +120,9 @@ GEMM_CLASS_PATTERNS = (            # projection -> substring of the rocprofv3 ke
 
 def measured_gemm_traffic():
     """Fabric (L2 <-> Infinity Cache/HBM) bytes per GEMM launch of THIS workload (ESM-1b config 2) from the committed PMC passes
-    (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs of this very script, calibrated on the
-    LayerNorm kernel whose traffic is known exactly).  The newest profiles/rNN_hbm_traffic_pmc.json wins -- the ESM-MSA-1b files
+    (tools/pmc_traffic.sh: separate rocprofv3 --pmc runs of this very script; since round 6 from the request counters themselves --
+    reads = 128-B requests x 128, writes = requests x 64 as a lower bound, checked on kernels whose bytes are known exactly; the
+    LayerNorm-derived scale factors of rounds 1-5 made every read 22 % too high).  The newest profiles/rNN_hbm_traffic_pmc.json wins -- the ESM-MSA-1b files
     (rNN_msa_hbm_traffic_pmc.json) are another workload and are never read here.  Returns (launch-weighted bytes per launch,
     {projection: bytes per launch}, file name); (None, {}, None) when there is no file.  PMC counters cannot be collected from
     inside the timed process, so this is a committed measurement of the same command, not of the run that prints it."""
@@ -602,8 +603,9 @@ def main():
                                "traffic": traffic,
                                "traffic_ratio": (traffic / alg_avg) if (traffic and alg_avg) else None,
                                "traffic_dominant_kernel": (per[dom].get("measured_fabric_MB_per_launch", 0) * 1e6 or None) if dom else None,
-                               "traffic_note": "bytes/launch L2<->fabric (FETCH_SIZE + WRITE_SIZE in separate --pmc passes of this script, "
-                                               "calibrated on LayerNorm; committed file %s -- PMC cannot be read from inside the timed process), "
+                               "traffic_note": "bytes/launch L2<->fabric (read / write request counters in separate --pmc passes of this script: "
+                                               "reads = 128-B requests x 128, writes = requests x 64 and never below the output size; "
+                                               "committed file %s -- PMC cannot be read from inside the timed process), "
                                                "weighted by this run's launches per iteration over the four per-layer GEMMs; algorithmic bytes of "
                                                "the same launches, from the shapes: %.0f; per-kernel measured / algorithmic in per_kernel[*].traffic_ratio"
                                                % (traffic_src, alg_avg or 0),

@@ -295,6 +295,10 @@ int pg_dbg_gemm(int device, int precision, const float* x, const float* w, const
  * of 64 above 256); variant 1 =
  * lockstep kernel, 2 = ping-pong kernel; epi: 0 bf16 out, 1 bf16+gelu, 2 fp32 residual, 3 fp32, 4 fp32+gelu */
 int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int iters, double* avg_ms);
+/* round 6: gemm_rowln.hip (out-projection of d_model = 768 with the next LayerNorm in its epilogue) against the two launches it
+ * replaces: ms[0] fused, ms[1] its main loop alone, ms[2] four half-steps + epilogue, ms[3] residual GEMM (256-column tiles),
+ * ms[4] LayerNorm kernel; max_diff 0 = x and h bit-identical between the two paths. */
+int pg_dbg_rowln_bench(int device, int M, int K, int iters, double* ms, double* max_diff);
 /* round-5 ablation: QKV projection + attention of B sequences of T in {32, 64, 128, 256} tokens as ONE launch (the fused
  * projection-attention kernel of the MSA column block, one head per 256 x 192 tile) against the two launches of the ESM-1b path;
  * ms[0] fused, ms[1] projection, ms[2] attention (HIP events, `iters` launches each); max_diff = max |fused - unfused| context */

@@ -110,6 +110,7 @@ SIGNATURES = [
     ("pg_prof_get_kernels", c_int, [c_void_p, c_char_p, c_char_p, c_int]),
     ("pg_dbg_gemm", c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     ("pg_dbg_gemm_bench", c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double)]),
+    ("pg_dbg_rowln_bench", c_int, [c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double)]),
     ("pg_dbg_qkv_attention_bench", c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double)]),
     ("pg_dbg_layernorm", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
     ("pg_dbg_attention", c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int]),

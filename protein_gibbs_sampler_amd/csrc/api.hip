@@ -658,6 +658,85 @@ int pg_dbg_gemm_bench(int device, int M, int N, int K, int epi, int variant, int
   return PG_OK;
 }
 
+// round 6: the full-row out-projection + LayerNorm kernel (gemm_rowln.hip) against the two launches it replaces, on synthetic operands
+// of d_model = 768: ms[0] fused kernel, ms[1] its main loop alone, ms[2] four half-steps + its epilogue, ms[3] residual GEMM on
+// 256-column tiles (default dispatch), ms[4] LayerNorm kernel; max_diff = max |h fused - h unfused| over the 16-bit rows (0: bit-identical).
+int pg_dbg_rowln_bench(int device, int M, int K, int iters, double* ms, double* max_diff) {
+  if (!ms || M < 256 || K % 64 || K < 128 || iters < 1) return fail(PG_ERR_INVALID, "pg_dbg_rowln_bench: bad argument");
+  DeviceGuard g(-1);
+  int rc = dbg_device(device);
+  if (rc) return rc;
+  const int N = 768, Mp = round_up(M, kRowPad);
+  Tmp t;
+  float* f = (float*)t.get((size_t)std::max(Mp, N) * std::max(K, N) * 4);
+  bf16_t* ba = (bf16_t*)t.get((size_t)Mp * K * 2);
+  bf16_t* bw = (bf16_t*)t.get((size_t)N * K * 2);
+  float* db = (float*)t.get((size_t)N * 4 * 3);
+  float* x0 = (float*)t.get((size_t)Mp * N * 4);
+  float* x1 = (float*)t.get((size_t)Mp * N * 4);
+  float* x2 = (float*)t.get((size_t)Mp * N * 4);
+  bf16_t* h1 = (bf16_t*)t.get((size_t)Mp * N * 2);
+  bf16_t* h2 = (bf16_t*)t.get((size_t)Mp * N * 2);
+  if (!f || !ba || !bw || !db || !x0 || !x1 || !x2 || !h1 || !h2) return fail(PG_ERR_HIP, "hipMalloc failed");
+  std::vector<float> hbuf((size_t)std::max(Mp, N) * std::max(K, N));
+  uint32_t st = 4242u;
+  for (auto& v : hbuf) { st = st * 1664525u + 1013904223u; v = ((st >> 8) * (1.0f / 8388608.0f) - 1.0f); }
+  PG_HIP(hipMemcpy(f, hbuf.data(), hbuf.size() * 4, hipMemcpyHostToDevice));
+  if ((rc = launch_f32_to_bf16(nullptr, f, ba, (int64_t)Mp * K, 1.f))) return rc;
+  if ((rc = launch_f32_to_bf16(nullptr, f + 977, bw, (int64_t)N * K, 0.05f))) return rc;
+  PG_HIP(hipMemcpy(db, hbuf.data() + 31, (size_t)N * 4 * 3, hipMemcpyHostToDevice));       // bias | gamma | beta
+  PG_HIP(hipMemcpy(x0, hbuf.data() + 5, (size_t)Mp * N * 4, hipMemcpyHostToDevice));
+  const float *gam = db + N, *bet = db + 2 * N;
+  hipEvent_t a, b;
+  PG_HIP(hipEventCreate(&a));
+  PG_HIP(hipEventCreate(&b));
+  auto timeit = [&](auto&& fn, double* out) -> int {
+    int r;
+    for (int i = 0; i < 2; ++i) if ((r = fn())) return r;
+    PG_HIP(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) if ((r = fn())) return r;
+    PG_HIP(hipEventRecord(b, nullptr));
+    PG_HIP(hipEventSynchronize(b));
+    float e = 0;
+    PG_HIP(hipEventElapsedTime(&e, a, b));
+    *out = e / iters;
+    return 0;
+  };
+  // correctness first: one application of each path to the same x
+  PG_HIP(hipMemcpy(x1, x0, (size_t)Mp * N * 4, hipMemcpyDeviceToDevice));
+  PG_HIP(hipMemcpy(x2, x0, (size_t)Mp * N * 4, hipMemcpyDeviceToDevice));
+  if ((rc = launch_gemm_rowln(nullptr, ba, bw, db, x1, gam, bet, h1, M, Mp, K, K, K, 1e-5f))) return rc;
+  if ((rc = launch_gemm_bf16(nullptr, ba, bw, db, x2, Mp, N, K, K, K, N, EPI_F32_RESID, nullptr, 0, M))) return rc;
+  if ((rc = launch_layernorm_bf16(nullptr, x2, gam, bet, h2, M, N, 1e-5f))) return rc;
+  PG_HIP(hipDeviceSynchronize());
+  if (max_diff) {
+    std::vector<uint16_t> c1((size_t)M * N), c2((size_t)M * N);
+    std::vector<float> y1((size_t)M * N), y2((size_t)M * N);
+    PG_HIP(hipMemcpy(c1.data(), h1, c1.size() * 2, hipMemcpyDeviceToHost));
+    PG_HIP(hipMemcpy(c2.data(), h2, c2.size() * 2, hipMemcpyDeviceToHost));
+    PG_HIP(hipMemcpy(y1.data(), x1, y1.size() * 4, hipMemcpyDeviceToHost));
+    PG_HIP(hipMemcpy(y2.data(), x2, y2.size() * 4, hipMemcpyDeviceToHost));
+    double md = 0;
+    for (size_t i = 0; i < c1.size(); ++i) {
+      if (c1[i] != c2[i]) md = std::max(md, 1.0 + std::fabs((double)bf16_to_f32(c1[i]) - (double)bf16_to_f32(c2[i])));
+      if (memcmp(&y1[i], &y2[i], 4)) md = std::max(md, 2.0 + std::fabs((double)y1[i] - (double)y2[i]));
+    }
+    *max_diff = md;
+  }
+  if ((rc = timeit([&] { return launch_gemm_rowln(nullptr, ba, bw, db, x1, gam, bet, h1, M, Mp, K, K, K, 1e-5f); }, ms + 0))) return rc;
+  if ((rc = timeit([&] { return launch_gemm_rowln(nullptr, ba, bw, db, x1, gam, bet, h1, M, Mp, K, K, K, 1e-5f, 0, 0, 1); }, ms + 1))) return rc;
+  if ((rc = timeit([&] { return launch_gemm_rowln(nullptr, ba, bw, db, x1, gam, bet, h1, M, Mp, K, K, K, 1e-5f, 0, 0, 2); }, ms + 2))) return rc;
+  if (const char* e = getenv("PGIBBS_ROWLN_BENCH_ABL")) {      // timing ablation of the epilogue in place of ms[2]
+    const int abl = atoi(e);
+    if ((rc = timeit([&] { return launch_gemm_rowln(nullptr, ba, bw, db, x1, gam, bet, h1, M, Mp, K, K, K, 1e-5f, 0, 0, abl); }, ms + 2))) return rc;
+  }
+  if ((rc = timeit([&] { return launch_gemm_bf16(nullptr, ba, bw, db, x2, Mp, N, K, K, K, N, EPI_F32_RESID, nullptr, 0, M); }, ms + 3))) return rc;
+  if ((rc = timeit([&] { return launch_layernorm_bf16(nullptr, x2, gam, bet, h2, M, N, 1e-5f); }, ms + 4))) return rc;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return PG_OK;
+}
+
 // round 5 ablation ("QKV projection fused with attention for ESM-1b"): the fused kernel that exists --
 // gemm_colattn_kernel<16> with one "column" per chain IS projection + attention of whole sequences of T = 256 tokens, one head per
 // 256 x 192 tile, the fusion's best case (16 query blocks on 16 waves, no 17th block, no padded rows) -- against the two launches it

@@ -581,6 +581,11 @@ per_layer:
 int Engine::resid_gemm_ln(const bf16_t* a, const DenseW& W, float* x, int M_rows, int64_t M_real, int lda, const LnW& ln, bf16_t* h,
                           float* ws, size_t ws_bytes, int prof_class, int colmajor_R, int colmajor_C) {
   const int d = W.N, K = W.K;
+  // d_model = 768, K <= 1024 (ESM-MSA-1b's attention out-projections) on big batches: one launch whose tiles span whole rows and
+  // normalise them in the epilogue (gemm_rowln.hip; same bits as the two launches below, so the choice is free)
+  static const int64_t rowln_min = [] { const char* e = getenv("PGIBBS_ROWLN_MIN_ROWS"); return e ? atoll(e) : 16384LL; }();
+  if (!strict() && M_real >= rowln_min && M_real <= M_rows && OPS(gemm_rowln_ok, M_rows, d, K))
+    return timed(prof_class, [&] { return OPS(launch_gemm_rowln, stream, a, W.w, W.b, x, ln.g, ln.b, h, (int)M_real, M_rows, K, lda, K, cfg.layer_norm_eps, colmajor_R, colmajor_C); });
   int rc = timed(prof_class, [&] { return OPS(launch_gemm_bf16, stream, a, W.w, W.b, x, M_rows, d, K, lda, K, d, EPI_F32_RESID, ws, ws_bytes, (int)M_real); });
   if (rc) return rc;
   return timed(PC_LN, [&] { return OPS(launch_layernorm_bf16, stream, x, ln.g, ln.b, h, M_real, d, cfg.layer_norm_eps, false, colmajor_R, colmajor_C); });

@@ -2,22 +2,27 @@
 # Fabric (L2 <-> Infinity Cache / HBM) traffic per kernel from PMC counters, separate --pmc passes as the MI355X guide prescribes
 # (FETCH_SIZE and WRITE_SIZE do not fit one pass), run on the GPU box:
 #   tools/pmc_traffic.sh TAG   -> gpurun_out/traffic_TAG.json
-# FETCH_SIZE / WRITE_SIZE are mis-scaled on gfx950 (guide: FETCH_SIZE counts a wide coalesced stream's 128-B requests at 64 B;
-# WRITE_SIZE = (WRREQ - WRREQ_64B) * 32 + WRREQ_64B * 64 knows no 128-B request either), so both are CALIBRATED on kernels whose
-# traffic is known exactly -- and since round 6 the write side separately per store class (one LayerNorm-derived
-# factor had fc1 "writing" 577 MB of a 676 MB output):
-#   reads            layernorm_bf16_kernel        reads  M*d*4
-#   16-bit stores    layernorm_bf16_kernel        writes M*d*2          (LayerNorm rows, bf16 GEMM epilogues, attention context)
-#   fp32 stores      embed_ln_kernel              writes M*d*4 (+ M*d*2 of 16-bit rows, priced with the factor above)
-#                                                                       (residual GEMM epilogues)
-# Two further passes read the 32-byte-unit DRAM counters (TCC_EA0_RDREQ_DRAM_32B / TCC_EA0_WRREQ_WRITE_DRAM_32B: bytes = 32 x count,
-# no calibration) beside the request counters they refine; the JSON carries both views.  Every kernel whose MEASURED bytes fall
-# below its ALGORITHMIC bytes (operands read once, outputs written once) is flagged: a calibration that says so is wrong.
+# Round 6: no more LayerNorm-derived scale factors.  The request counters behind the two derived ones say what
+# they count on gfx950 (profiles/r06_hbm_traffic_pmc.json keeps them per kernel):
+#   reads   every request is a 128-B request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ) that FETCH_SIZE tallies at 64 B -- the guide's
+#           "double it".  bytes = RDREQ_128B x 128 + RDREQ_64B x 64 + rest x 32.  Check: attention_kernel reads q | k | v exactly
+#           once -> 507.4 MB measured against 507.2 MB algorithmic.  (LayerNorm, the kernel rounds 1-5 calibrated on, reads only
+#           277 of its 338 MB through the fabric: the rest of the rows the producer GEMM just wrote are still in the 32 MB of L2 --
+#           so every "calibrated" read figure of rounds 1-5 was 22 % too high.)
+#   writes  every request is tallied as a 64-B request (TCC_EA0_WRREQ_64B == TCC_EA0_WRREQ): bytes >= WRREQ x 64 = WRITE_SIZE KiB x
+#           1024.  Exact for embed_ln (507.2 of 507.2 MB), the QKV GEMM (507.3 / 507.2), attention (169.1 / 169.1), out-projection
+#           and fc2 (338.3 / 338.2): three store patterns, 16-bit and fp32.  Two kernels come out BELOW their output size --
+#           LayerNorm 138.5 of 169.1 MB (the last ~31 MB are still dirty in L2 when the dispatch ends) and fc1 473 of 676 MB (same
+#           store instruction as the QKV GEMM; some of its full 128-B lines leave L2 as ONE request, which the counter tallies at
+#           64 B -- there is no TCC_EA0_WRREQ_128B to tell) -- so the write figure is a LOWER BOUND, and a kernel whose bound falls
+#           below its algorithmic bytes is flagged and reported at the algorithmic bytes (it cannot have written less).
+# The 32-byte-unit DRAM counters (TCC_EA0_RDREQ_DRAM_32B / TCC_EA0_WRREQ_WRITE_DRAM_32B) are collected beside them (same
+# blind spots: a 128-B request counts 2 units).  A last pass reads TCC_HIT / TCC_MISS: the L2 hit rate per kernel.
 TAG=${1:-r01}; ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-strict --no-fp16 --no-msa --no-host-entry --no-shard-proxy --layers 3"
 i=0
-for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum" "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rm -rf /tmp/traf_${TAG}_$i
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/traf_${TAG}_$i -o p -- $BENCH > /tmp/traf_run_$i.log 2>&1 || tail -3 /tmp/traf_run_$i.log
@@ -27,7 +32,7 @@ python - "$TAG" "$ROOT" <<'PY'
 import csv, glob, json, sys, collections
 tag, root = sys.argv[1:3]
 raw = collections.defaultdict(dict)          # counter -> kernel -> (mean per launch, launches)
-for i in (1, 2, 3, 4):
+for i in (1, 2, 3, 4, 5):
     f = glob.glob("/tmp/traf_%s_%d/**/*counter_collection.csv" % (tag, i), recursive=True)
     if not f:
         print("pass %d: no counter csv" % i); continue
@@ -43,25 +48,36 @@ def one(pat, c):
     ks = [k for k in raw.get(c, {}) if pat in k]
     return raw[c][ks[0]][0] if ks else None
 ln = [k for k in raw["FETCH_SIZE"] if "layernorm_bf16_kernel" in k][0]
+att = [k for k in raw["FETCH_SIZE"] if "attention_kernel" in k]
 emb = [k for k in raw["FETCH_SIZE"] if "embed_ln_kernel" in k]
-f_scale = (M * d * 4) / raw["FETCH_SIZE"][ln][0]                 # bytes per FETCH_SIZE unit
-w16 = (M * d * 2) / raw["WRITE_SIZE"][ln][0]                     # bytes per WRITE_SIZE unit, 16-bit row stores
-w32 = None
-if emb and raw["WRITE_SIZE"].get(emb[0]):
-    # embed_ln writes the fp32 residual rows (M*d*4) and the first LayerNorm's 16-bit rows (M*d*2): if the two store classes were
-    # counted alike, its WRITE_SIZE would be 3x LayerNorm's; what is left after the 16-bit share prices the fp32 stores
-    w_emb = raw["WRITE_SIZE"][emb[0]][0]
-    fp32_units = w_emb - (M * d * 2) / w16
-    if fp32_units > 0:
-        w32 = (M * d * 4) / fp32_units
-out = {"calibration": {"read": {"kernel": ln, "bytes_per_FETCH_SIZE_unit": f_scale, "known_read_bytes": M * d * 4},
-                       "write_16bit_stores": {"kernel": ln, "bytes_per_WRITE_SIZE_unit": w16, "known_write_bytes": M * d * 2},
-                       "write_fp32_stores": {"kernel": emb[0] if emb else None, "bytes_per_WRITE_SIZE_unit": w32,
-                                             "known_write_bytes": M * d * 4, "beside": "M*d*2 of 16-bit rows priced with the 16-bit factor"},
-                       # kept for readers of the r01-r05 files
-                       "kernel": ln, "bytes_per_FETCH_SIZE_unit": f_scale, "bytes_per_WRITE_SIZE_unit": w16,
-                       "known_read_bytes": M * d * 4, "known_write_bytes": M * d * 2},
-       "kernels": {}}
+def rd_bytes(k):
+    """fabric read bytes of kernel k from the request counters (pass 3); FETCH_SIZE x 2 KiB when that pass is missing"""
+    r = raw.get("TCC_EA0_RDREQ_sum", {}).get(k)
+    if r is None:
+        return raw["FETCH_SIZE"][k][0] * 2048.0
+    r128 = raw.get("TCC_EA0_RDREQ_128B_sum", {}).get(k, (0.0, 0))[0]
+    r64 = raw.get("TCC_EA0_RDREQ_64B_sum", {}).get(k, (0.0, 0))[0]
+    return r128 * 128 + r64 * 64 + max(0.0, r[0] - r128 - r64) * 32
+def wr_bytes(k):
+    """fabric write bytes, LOWER BOUND (requests of 128 B are tallied at 64 B)"""
+    w = raw.get("TCC_EA0_WRREQ_sum", {}).get(k)
+    if w is None:
+        return raw["WRITE_SIZE"].get(k, (0.0, 0))[0] * 1024.0
+    w64 = raw.get("TCC_EA0_WRREQ_64B_sum", {}).get(k, (0.0, 0))[0]
+    return w64 * 64 + max(0.0, w[0] - w64) * 32
+checks = {"attention_read": {"kernel": att[0] if att else None, "measured_MB": rd_bytes(att[0]) / 1e6 if att else None,
+                             "known_MB": M * 3 * d * 2 / 1e6, "why": "q | k | v are read exactly once"},
+          "embed_ln_write": {"kernel": emb[0] if emb else None, "measured_MB": wr_bytes(emb[0]) / 1e6 if emb else None,
+                             "known_MB": M * d * 6 / 1e6, "why": "fp32 residual rows + the first LayerNorm's 16-bit rows"},
+          "layernorm_read": {"kernel": ln, "measured_MB": rd_bytes(ln) / 1e6, "known_MB": M * d * 4 / 1e6,
+                             "why": "BELOW its algorithmic bytes: the tail of the rows the producer GEMM wrote is still in the 32 MB of "
+                                    "L2 -- the kernel rounds 1-5 calibrated FETCH_SIZE on (their read figures were 22 % too high)"},
+          "layernorm_write": {"kernel": ln, "measured_MB": wr_bytes(ln) / 1e6, "known_MB": M * d * 2 / 1e6,
+                              "why": "BELOW its output: ~31 MB are still dirty in L2 when the dispatch ends"}}
+out = {"method": "reads = TCC_EA0_RDREQ_128B x 128 + _64B x 64 + rest x 32 bytes (FETCH_SIZE tallies the 128-B requests at 64 B: the guide's "
+                 "'double it'); writes >= TCC_EA0_WRREQ x 64 bytes = WRITE_SIZE KiB x 1024 (a LOWER BOUND: 128-B write requests are "
+                 "tallied at 64 B and no counter tells them apart); no scale factors -- see `checks`",
+       "checks": checks, "kernels": {}}
 # projection -> kernel name of this build (bench.py's GEMM_CLASS_PATTERNS; the JSON's table wins there)
 pats = (("gemm_qkv", "gemm_bf16_w16_kernel<0"), ("gemm_fc1", "gemm_bf16_w16_kernel<1"),
         ("gemm_out", "gemm_bf16_pp_kernel<2, 0, 4"), ("gemm_fc2", "gemm_bf16_pp_kernel<2, 0, 2"))
@@ -81,35 +97,35 @@ for k in raw["FETCH_SIZE"]:
     fr, n = raw["FETCH_SIZE"][k]
     wr = raw["WRITE_SIZE"].get(k, (0.0, 0))[0]
     cls = by_kernel.get(k)
-    store = alg[cls][2] if cls else "16"
-    if store == "32" and w32:
-        w_bytes, w_how = wr * w32, "fp32-store factor"
-    elif store == "mixed" and w32:
-        w_bytes, w_how = M * d * 2 + (wr - (M * d * 2) / w16) * w32, "16-bit share at the 16-bit factor, rest at the fp32-store factor"
-    else:
-        w_bytes, w_how = wr * w16, "16-bit-store factor"
-    e = {"launches": n, "read_MB_per_launch": fr * f_scale / 1e6, "write_MB_per_launch": w_bytes / 1e6, "write_calibration": w_how,
-         "raw_FETCH_SIZE": fr, "raw_WRITE_SIZE": wr}
+    e = {"launches": n, "read_MB_per_launch": rd_bytes(k) / 1e6, "write_MB_per_launch": wr_bytes(k) / 1e6,
+         "write_MB_lower_bound": wr_bytes(k) / 1e6, "raw_FETCH_SIZE": fr, "raw_WRITE_SIZE": wr}
     rd32 = raw.get("TCC_EA0_RDREQ_DRAM_32B_sum", {}).get(k)
     wr32 = raw.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", {}).get(k)
     if rd32: e["dram_read_MB_per_launch_32B_units"] = rd32[0] * 32 / 1e6
     if wr32: e["dram_write_MB_per_launch_32B_units"] = wr32[0] * 32 / 1e6
-    for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"):
+    for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum",
+              "TCC_HIT_sum", "TCC_MISS_sum"):
         if raw.get(c, {}).get(k): e["raw_" + c] = raw[c][k][0]
+    if "raw_TCC_HIT_sum" in e and e["raw_TCC_HIT_sum"] + e.get("raw_TCC_MISS_sum", 0) > 0:
+        e["l2_hit"] = e["raw_TCC_HIT_sum"] / (e["raw_TCC_HIT_sum"] + e.get("raw_TCC_MISS_sum", 0))
     if cls:
         a_rd, a_wr, _ = alg[cls]
         e["class"] = cls
         e["algorithmic_read_MB"] = None if a_rd is None else a_rd / 1e6
         e["algorithmic_write_MB"] = a_wr / 1e6
         if a_rd is not None and e["read_MB_per_launch"] < 0.98 * a_rd / 1e6:
-            flags.append("%s (%s): measured read %.0f MB < algorithmic %.0f MB" % (cls, k[:60], e["read_MB_per_launch"], a_rd / 1e6))
+            flags.append("%s (%s): fabric reads %.0f MB < algorithmic %.0f MB (the rest hit in L2)" % (cls, k[:60], e["read_MB_per_launch"], a_rd / 1e6))
+            e["read_below_algorithmic"] = "L2 hits on rows the previous kernel left in the 32 MB of L2"
         if e["write_MB_per_launch"] < 0.98 * a_wr / 1e6:
-            flags.append("%s (%s): measured write %.0f MB < algorithmic %.0f MB" % (cls, k[:60], e["write_MB_per_launch"], a_wr / 1e6))
+            flags.append("%s (%s): write lower bound %.0f MB < output %.0f MB -> reported at the output size" % (cls, k[:60], e["write_MB_per_launch"], a_wr / 1e6))
+            e["write_below_algorithmic"] = ("lower bound %.1f MB (128-B write requests tallied at 64 B / lines still dirty in L2 at the end of "
+                                            "the dispatch); reported at the algorithmic %.1f MB" % (e["write_MB_per_launch"], a_wr / 1e6))
+            e["write_MB_per_launch"] = a_wr / 1e6
     out["kernels"][k] = e
 out["classes"] = classes
 out["measured_below_algorithmic"] = flags
 out["command"] = ("bench.py --steps 1 --warmup 0 --layers 3 --no-shard-proxy (config 2 shapes: 256 chains x T=258), one rocprofv3 --pmc pass per "
-                  "counter group: FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_DRAM_32B + request sizes | TCC_EA0_WRREQ_WRITE_DRAM_32B + request sizes")
+                  "counter group: FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ_DRAM_32B + request sizes | TCC_EA0_WRREQ_WRITE_DRAM_32B + request sizes | TCC_HIT, TCC_MISS")
 json.dump(out, open("%s/gpurun_out/traffic_%s.json" % (root, tag), "w"), indent=1)
 print("%-62s %3s %9s %9s | %9s %9s | %9s %9s" % ("kernel", "n", "read MB", "write MB", "alg read", "alg write", "rd 32B-u", "wr 32B-u"))
 for k, v in out["kernels"].items():
@@ -117,6 +133,8 @@ for k, v in out["kernels"].items():
           "%.1f" % v["algorithmic_read_MB"] if v.get("algorithmic_read_MB") else "-", "%.1f" % v["algorithmic_write_MB"] if v.get("algorithmic_write_MB") else "-",
           "%.1f" % v["dram_read_MB_per_launch_32B_units"] if "dram_read_MB_per_launch_32B_units" in v else "-",
           "%.1f" % v["dram_write_MB_per_launch_32B_units"] if "dram_write_MB_per_launch_32B_units" in v else "-"))
-print("calibration: read %.1f B/unit (LayerNorm), write 16-bit stores %.1f B/unit (LayerNorm), fp32 stores %s B/unit (embed_ln)" % (f_scale, w16, "%.1f" % w32 if w32 else "n/a"))
-print("MEASURED BELOW ALGORITHMIC:", flags if flags else "none")
+for name, c in checks.items():
+    print("check %-16s measured %8.1f MB  known %8.1f MB  (%s)" % (name, c["measured_MB"] or 0, c["known_MB"], c["why"][:90]))
+print("MEASURED BELOW ALGORITHMIC (flagged, see the JSON):")
+for f_ in flags: print("  ", f_)
 PY
