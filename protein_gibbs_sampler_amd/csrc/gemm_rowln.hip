@@ -162,8 +162,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const bf16_t* __restric
   // ---------------- epilogue: three phases of row blocks {0,1} {2,3} {4,5,6} ----------------
   // Per phase: (1) every wave stages acc + bias of the phase's row blocks for its 96 columns; (2) the NEXT phase's residual rows are
   // requested (the accumulators just staged are dead: their registers hold the loads), so only the first phase waits for HBM;
-  // (3) wave w finishes rows w, w + 8, ...: x_old + staged row -> x (fp32, streamed), LayerNorm of all its rows interleaved
-  // (ln_inplace_rows), 16-bit rows of h.
+  // (3) wave w finishes rows w, w + 8, ...: x_old + staged row -> x (fp32, streamed), ln_inplace, 16-bit row of h.
   auto load_x = [&](auto J0c, auto RPWc, float4 (&xo)[decltype(RPWc)::value][3]) {
     constexpr int J0 = decltype(J0c)::value, RPW = decltype(RPWc)::value;
 #pragma unroll
@@ -209,18 +208,24 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const bf16_t* __restric
         }
       }
     }
-    if (ABL != 12) ln_inplace_rows<RPW, 3>(v, lane, eps, gamma, beta);
+    // the stand-alone LayerNorm kernel's own routine, row by row (ln_row.h: the ONLY definition of the arithmetic -- an interleaved
+    // restatement of it, `ln_inplace_rows`, was measured to differ in the last bit of some h values and to buy nothing: the
+    // LayerNorm arithmetic is free here, profiles/r06_rowln_epilogue_ablation.txt)
 #pragma unroll
     for (int it = 0; it < RPW; ++it) {
       const int g = m0 + J0 * 16 + wave + it * 8;
       if (g >= row_lo && g < m_live) {
+        float4 w8[kMaxCh];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w8[c] = v[it][c];
+        if (ABL != 12) ln_inplace(w8, N / 4, lane, N, eps, gamma, beta);
         size_t hrow = (size_t)g;
         if (cm_R > 0) {                                                    // token row (b R + r) C + c -> operand row (b C + c) R + r
           const int br = g / cm_C, cc = g - br * cm_C, bb = br / cm_R, rr = br - bb * cm_R;
           hrow = ((size_t)bb * cm_C + cc) * cm_R + rr;
         }
-        if (ABL == 14) { asm volatile("" ::"v"(v[it][0].x), "v"(v[it][1].y), "v"(v[it][2].z)); }
-        else store_row16<3>(h + hrow * N, v[it], lane);
+        if (ABL == 14) { asm volatile("" ::"v"(w8[0].x), "v"(w8[1].y), "v"(w8[2].z)); }
+        else store_row_bf16(h + hrow * N, w8, N / 4, lane);
       }
     }
   };

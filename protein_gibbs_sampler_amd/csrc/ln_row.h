@@ -43,67 +43,6 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[kMaxCh], int nch4, int la
     }
 }
 
-// The same LayerNorm on NR rows at once (one wave, NCH float4 chunks per lane and row: d = 256 NCH): every row goes through exactly
-// ln_inplace's operations in ln_inplace's order -- the rows are only interleaved, so that the 12 dependent cross-lane steps of one
-// row's two reductions overlap with the other rows' (a wave that finishes several rows of a GEMM tile: gemm_rowln.hip).  Same bits as
-// NR calls of ln_inplace (tests/test_gpu_msa.py compares the fused kernel with the stand-alone LayerNorm kernel bit for bit).
-template <int NR, int NCH>
-__device__ __forceinline__ void ln_inplace_rows(float4 (&v)[NR][NCH], int lane, float eps, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta) {
-  constexpr int d = NCH * 256;
-  float s[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    s[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) s[r] = __fadd_rn(s[r], __fadd_rn(__fadd_rn(v[r][i].x, v[r][i].y), __fadd_rn(v[r][i].z, v[r][i].w)));
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int r = 0; r < NR; ++r) s[r] = __fadd_rn(s[r], __shfl_xor(s[r], o));
-  float q[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const float mean = __fdiv_rn(s[r], (float)d);
-    q[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      float4& t = v[r][i];
-      t.x = __fsub_rn(t.x, mean); t.y = __fsub_rn(t.y, mean); t.z = __fsub_rn(t.z, mean); t.w = __fsub_rn(t.w, mean);
-      q[r] = __fadd_rn(q[r], __fadd_rn(__fmaf_rn(t.x, t.x, __fmul_rn(t.y, t.y)), __fmaf_rn(t.z, t.z, __fmul_rn(t.w, t.w))));
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int r = 0; r < NR; ++r) q[r] = __fadd_rn(q[r], __shfl_xor(q[r], o));
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const float4 g = ((const float4*)gamma)[lane + 64 * i], b = ((const float4*)beta)[lane + 64 * i];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const float rstd = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(q[r], (float)d), eps)));
-      float4& t = v[r][i];
-      t.x = __fmaf_rn(__fmul_rn(t.x, rstd), g.x, b.x);
-      t.y = __fmaf_rn(__fmul_rn(t.y, rstd), g.y, b.y);
-      t.z = __fmaf_rn(__fmul_rn(t.z, rstd), g.z, b.z);
-      t.w = __fmaf_rn(__fmul_rn(t.w, rstd), g.w, b.w);
-    }
-  }
-}
-// one normalised row (NCH chunks per lane) as 16-bit values: store_row_bf16's plain form
-template <int NCH>
-__device__ __forceinline__ void store_row16(bf16_t* dst, const float4 (&v)[NCH], int lane) {
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    uint2 p;
-    p.x = pack_op2(v[i].x, v[i].y);
-    p.y = pack_op2(v[i].z, v[i].w);
-    ((uint2*)dst)[lane + 64 * i] = p;
-  }
-}
-
 // hi = bf16(v).  split3 (strict precision mode): the row becomes the split-bf16 activation operand of 3 * d values, interleaved
 // in groups of 32 columns: group g = [lo(32) | hi(32) | hi(32)] of columns 32g .. 32g+31, lo = bf16(v - hi).  Against a weight
 // row packed [hi | lo | hi] the same way, one bf16 GEMM over K' = 3 d sums, per 32 columns and in this order,

@@ -297,3 +297,15 @@ def test_full_row_out_projection_with_layernorm_epilogue_is_bit_identical(tmp_pa
     for k in res["0"].files:
         assert np.isfinite(res["0"][k]).all() and res["0"][k].std() > 0.1
         assert (res["1"][k].view(np.uint32) == res["0"][k].view(np.uint32)).all(), k
+
+
+def test_full_row_kernel_against_the_two_launches_on_raw_operands():
+    """pg_dbg_rowln_bench: gemm_rowln.hip and residual GEMM + LayerNorm kernel applied once to the same synthetic operands (16 448 and
+    65 664 token rows: a last row panel shifted against the padding, K = 768 and 256): x (fp32) and h (16-bit) equal bit for bit."""
+    import ctypes
+    L = _lib.lib()
+    for M, K in ((16448, 768), (65664, 768), (5000, 256)):
+        ms = (ctypes.c_double * 5)()
+        md = ctypes.c_double(-1)
+        _lib.check(L.pg_dbg_rowln_bench(0, M, K, 1, ms, ctypes.byref(md)))
+        assert md.value == 0.0, (M, K, md.value)
